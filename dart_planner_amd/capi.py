@@ -1,0 +1,213 @@
+"""ctypes binding of libse3mpc.so (include/se3mpc.h) -- raw pointers in, status codes out.
+
+This is the only place the package touches the C ABI.  There is NO fallback: if the HIP library
+has not been built (``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C dart_planner_amd/csrc``) loading raises :class:`Se3mpcLibraryError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIBRARY = os.path.join(_HERE, "libse3mpc.so")
+
+SE3MPC_MAX_HORIZON = 64
+SE3MPC_MAX_CORRECTIONS = 10
+SE3MPC_MAX_SPHERES = 256
+
+STATUS_NAMES = {0: "SE3MPC_OK", -1: "SE3MPC_ERR_NULL", -2: "SE3MPC_ERR_HORIZON", -3: "SE3MPC_ERR_SHAPE",
+                -4: "SE3MPC_ERR_PARAM", -5: "SE3MPC_ERR_WORKSPACE", -6: "SE3MPC_ERR_LAUNCH",
+                -7: "SE3MPC_ERR_NO_DEVICE"}
+TASK_MESSAGES = {1: "CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL",
+                 2: "CONVERGENCE: RELATIVE REDUCTION OF F <= FACTR*EPSMCH",
+                 3: "STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT",
+                 4: "STOP: TOTAL NO. OF F,G EVALUATIONS EXCEEDS LIMIT",
+                 5: "ABNORMAL: "}
+
+
+class Se3mpcLibraryError(RuntimeError):
+    """libse3mpc.so is missing or does not export the ABI of include/se3mpc.h."""
+
+
+class Se3mpcError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, fn: str, status: int, detail: str = ""):
+        self.status = status
+        super().__init__(f"{fn} -> {STATUS_NAMES.get(status, status)}" + (f": {detail}" if detail else ""))
+
+
+class Params(C.Structure):
+    """struct se3mpc_params (include/se3mpc.h) == SE3MPCConfig + ctor constants of the reference
+    (src/dart_planner/planning/se3_mpc_planner.py:36-79, :149-151), unit-stripped."""
+    _fields_ = [("horizon", C.c_int32), ("has_goal", C.c_int32), ("dt", C.c_double), ("mass", C.c_double),
+                ("gravity", C.c_double), ("position_weight", C.c_double), ("velocity_weight", C.c_double),
+                ("acceleration_weight", C.c_double), ("thrust_weight", C.c_double), ("terminal_factor", C.c_double),
+                ("position_bound", C.c_double), ("max_velocity", C.c_double), ("max_acceleration", C.c_double),
+                ("max_thrust", C.c_double), ("min_thrust", C.c_double), ("max_tilt_angle", C.c_double),
+                ("safety_margin", C.c_double), ("max_iterations", C.c_int32), ("max_corrections", C.c_int32),
+                ("max_linesearch", C.c_int32), ("max_fun", C.c_int32), ("pgtol", C.c_double), ("ftol", C.c_double)]
+
+    @classmethod
+    def reference_defaults(cls, **overrides) -> "Params":
+        """The reference defaults, computed here the same way se3mpc_default_params() does (the
+        test-suite checks the two agree)."""
+        p = cls(horizon=6, has_goal=1, dt=1.0 / 400.0, mass=1.5, gravity=9.81, position_weight=100.0,
+                velocity_weight=10.0, acceleration_weight=1.0, thrust_weight=0.1, terminal_factor=10.0,
+                position_bound=100.0, max_velocity=10.0, max_acceleration=15.0, max_thrust=25.0, min_thrust=2.0,
+                max_tilt_angle=math.pi / 4, safety_margin=1.5, max_iterations=15, max_corrections=10,
+                max_linesearch=20, max_fun=15000, pgtol=0.05, ftol=0.5)
+        for k, v in overrides.items():
+            if k not in dict(cls._fields_):
+                raise AttributeError(f"se3mpc_params has no field {k!r}")
+            setattr(p, k, v)
+        return p
+
+    def copy(self, **overrides) -> "Params":
+        q = Params()
+        C.memmove(C.byref(q), C.byref(self), C.sizeof(Params))
+        for k, v in overrides.items():
+            setattr(q, k, v)
+        return q
+
+    def as_dict(self) -> dict:
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SolveInfo(C.Structure):
+    """struct se3mpc_solve_info."""
+    _fields_ = [("fun", C.c_double), ("nit", C.c_int32), ("nfev", C.c_int32), ("status", C.c_int32),
+                ("task", C.c_int32)]
+
+
+_P = C.c_void_p
+_I = C.c_int
+_PP = C.POINTER(Params)
+
+# name -> argtypes after the leading (const se3mpc_params*) when `params` is True
+_TYPED_API = {
+    "init": (True, [_I, _I, _P, _P, _P, _I, _P, _P]),
+    "cost_grad": (True, [_I, _I, _P, _P, _P, _P, _P]),
+    "dynamics_residual": (True, [_I, _I, _P, _P, _P, _P, _P]),
+    "obstacle_residual": (True, [_I, _I, _P, _P, _I, _P, _P, _P, _P]),
+    "physical_constraints": (True, [_I, _I, _P, _P, _P]),
+    "extract": (True, [_I, _I, _P, _P, _P, _P, _P, _P]),
+    "rollout_cost_grad": (True, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    "is_plan_valid": (True, [_I, _I, _P, _P, _P, _P]),
+    "argmin": (False, [_I, _P, C.c_uint32, _P, _P]),
+    "transpose": (False, [_I, _I, _P, _I, _P, _I, _P]),
+    "solve": (True, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+_PLAIN_API = {
+    "se3mpc_abi_version": (C.c_int, []),
+    "se3mpc_last_error": (C.c_char_p, []),
+    "se3mpc_device_count": (C.c_int, []),
+    "se3mpc_default_params": (C.c_int, [_PP]),
+    "se3mpc_check_params": (C.c_int, [_PP]),
+    "se3mpc_set_rollout_variant": (C.c_int, [_I]),
+    "se3mpc_key_index": (C.c_uint32, [C.c_uint64]),
+    "se3mpc_key_cost": (C.c_float, [C.c_uint64]),
+}
+
+
+def exported_symbols() -> list:
+    """Every symbol include/se3mpc.h declares (the CPU test-suite checks the .so exports them)."""
+    names = list(_PLAIN_API)
+    for base in _TYPED_API:
+        names += [f"se3mpc_{base}_f32", f"se3mpc_{base}_f64"]
+    return names
+
+
+class Library:
+    """A loaded libse3mpc.so.  Methods take raw device addresses (ints) and return nothing;
+    a negative status raises :class:`Se3mpcError`."""
+
+    def __init__(self, path: Optional[str] = None):
+        self.path = path or os.environ.get("SE3MPC_LIBRARY", DEFAULT_LIBRARY)
+        if not os.path.exists(self.path):
+            raise Se3mpcLibraryError(
+                f"{self.path} not found: the HIP extension has not been built.  Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C dart_planner_amd/csrc`). "
+                "There is no CPU fallback.")
+        try:
+            self._dll = C.CDLL(self.path)
+        except OSError as e:  # pragma: no cover
+            raise Se3mpcLibraryError(f"cannot load {self.path}: {e}") from e
+        missing = [s for s in exported_symbols() if not hasattr(self._dll, s)]
+        if missing:
+            raise Se3mpcLibraryError(f"{self.path} does not export {missing}")
+        for name, (res, args) in _PLAIN_API.items():
+            fn = getattr(self._dll, name)
+            fn.restype, fn.argtypes = res, args
+        for base, (has_params, args) in _TYPED_API.items():
+            for suf in ("f32", "f64"):
+                fn = getattr(self._dll, f"se3mpc_{base}_{suf}")
+                fn.restype = C.c_int
+                fn.argtypes = ([_PP] if has_params else []) + args
+        if self._dll.se3mpc_abi_version() != 1:
+            raise Se3mpcLibraryError(f"{self.path}: ABI version {self._dll.se3mpc_abi_version()} != 1")
+
+    # -- plain entry points -----------------------------------------------------------------
+    def abi_version(self) -> int:
+        return self._dll.se3mpc_abi_version()
+
+    def last_error(self) -> str:
+        return (self._dll.se3mpc_last_error() or b"").decode()
+
+    def device_count(self) -> int:
+        return self._dll.se3mpc_device_count()
+
+    def default_params(self) -> Params:
+        p = Params()
+        self._check("se3mpc_default_params", self._dll.se3mpc_default_params(C.byref(p)))
+        return p
+
+    def check_params(self, p: Params) -> int:
+        return self._dll.se3mpc_check_params(C.byref(p))
+
+    def set_rollout_variant(self, variant: int) -> None:
+        self._check("se3mpc_set_rollout_variant", self._dll.se3mpc_set_rollout_variant(variant))
+
+    def key_index(self, key: int) -> int:
+        return self._dll.se3mpc_key_index(C.c_uint64(key))
+
+    def key_cost(self, key: int) -> float:
+        return self._dll.se3mpc_key_cost(C.c_uint64(key))
+
+    # -- typed entry points -----------------------------------------------------------------
+    def call(self, base: str, suffix: str, *args, params: Optional[Params] = None) -> None:
+        """Call se3mpc_<base>_<suffix>(params?, *args); raise on a negative status."""
+        fn = getattr(self._dll, f"se3mpc_{base}_{suffix}")
+        has_params = _TYPED_API[base][0]
+        if has_params:
+            if params is None:
+                raise TypeError(f"se3mpc_{base} needs params")
+            rc = fn(C.byref(params), *args)
+        else:
+            rc = fn(*args)
+        self._check(f"se3mpc_{base}_{suffix}", rc)
+
+    def call_status(self, base: str, suffix: str, *args, params: Optional[Params] = None) -> int:
+        """Same as :meth:`call` but returns the raw status (used by the error-behaviour tests)."""
+        fn = getattr(self._dll, f"se3mpc_{base}_{suffix}")
+        if _TYPED_API[base][0]:
+            return fn(C.byref(params) if params is not None else None, *args)
+        return fn(*args)
+
+    def _check(self, name: str, rc: int) -> None:
+        if rc != 0:
+            raise Se3mpcError(name, rc, self.last_error() if rc == -6 else "")
+
+
+_default: Optional[Library] = None
+
+
+def get_library() -> Library:
+    """The process-wide library handle (loads on first use; raises if it is not built)."""
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

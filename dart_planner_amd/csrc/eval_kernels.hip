@@ -1,0 +1,785 @@
+// eval_kernels.hip -- lane-layout ([row][b]) evaluation kernels of the SE(3) MPC path.
+//
+// One trajectory per lane: lane b of a wavefront reads element [row][b], so every load/store of
+// a wavefront is one contiguous, fully used 256-B (f32) segment.  All of these kernels are
+// HBM-streaming (1.7-10 flop/B, far below the fp32 ridge of ~20 flop/B); none has a dense
+// contraction, so none uses MFMA (the "12x12 linearised dynamics" of the brief is
+// a 2-FMA-per-axis LTI map).  Reference arithmetic: src/dart_planner/planning/se3_mpc_planner.py
+// ("planner.py" in the comments), unit-stripped.
+#include <hip/hip_runtime.h>
+
+#include "se3mpc_common.hpp"
+#include <se3mpc_wave_ops.hpp>
+
+namespace se3mpc {
+
+// ------------------------------------------------------------------------------------------
+// a3 + a4: cold start (planner.py:329-359) and optional projection into the box (:378-402)
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+                            const R* __restrict__ goal, int project, R* __restrict__ X) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N, N3 = 3 * q.N;
+  const R denom = (R)(N - 1 > 1 ? N - 1 : 1);
+  for (int a = 0; a < 3; ++a) {
+    const R p = p0[(size_t)a * ld + b];
+    const R v = v0[(size_t)a * ld + b];
+    const R g = q.has_goal ? goal[(size_t)a * ld + b] : p;
+    R prev = p;
+    for (int i = 0; i < N; ++i) {
+      R pi, vi;
+      if (q.has_goal) {
+        const R alpha = (R)i / denom;                       // planner.py:344
+        pi = ((R)1 - alpha) * p + alpha * g;                // planner.py:345-347
+        vi = (i == 0) ? v : (pi - prev) / q.dt;             // planner.py:339, :350
+      } else {
+        pi = p;                                             // planner.py:356
+        vi = (i == 0) ? v : (R)0;
+      }
+      prev = pi;
+      R ti = (a == 2) ? q.hover : (R)0;                     // planner.py:353
+      if (project) {
+        pi = fmin(fmax(pi, -q.pos_b), q.pos_b);
+        vi = fmin(fmax(vi, -q.v_max), q.v_max);
+        ti = (a == 2) ? fmin(fmax(ti, q.tz_lo), q.tz_hi) : ti;
+      }
+      X[(size_t)(3 * i + a) * ld + b] = pi;
+      X[(size_t)(N3 + 3 * i + a) * ld + b] = vi;
+      X[(size_t)(2 * N3 + 3 * i + a) * ld + b] = ti;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a5 + a6: objective (planner.py:516-550) and the reference's gradient (planner.py:552-580)
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R* __restrict__ goal,
+                                 R* __restrict__ f, R* __restrict__ g) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N, N3 = 3 * q.N;
+  R sp = 0, sv = 0, sa = 0, st = 0, sterm = 0;
+  for (int a = 0; a < 3; ++a) {
+    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
+    const R grav = (a == 2) ? q.grav : (R)0;
+    const R hov = (a == 2) ? q.hover : (R)0;
+#pragma unroll 4
+    for (int k = 0; k < N; ++k) {
+      const size_t rp = (size_t)(3 * k + a) * ld + b;
+      const size_t rv = (size_t)(N3 + 3 * k + a) * ld + b;
+      const size_t rt = (size_t)(2 * N3 + 3 * k + a) * ld + b;
+      const R x = X[rp], v = X[rv], t = X[rt];
+      const R e = x - gl;
+      const R acc = t * q.inv_mass - grav;                  // planner.py:535-537
+      const R dev = t - hov;                                // planner.py:542
+      sp += e * e;
+      sv += v * v;
+      sa += acc * acc;
+      st += dev * dev;
+      if (k == N - 1) sterm += e * e;                       // planner.py:546-548
+      if (g != nullptr) {
+        g[rp] = q.has_goal ? (R)2 * q.wp * e : (R)0;        // planner.py:567-570 (no terminal x10)
+        g[rv] = (R)2 * q.wv * v;                            // planner.py:573-574
+        g[rt] = (R)2 * q.wT * t;                            // planner.py:577-578 (no hover offset, no accel term)
+      }
+    }
+  }
+  R cost = q.wv * sv + q.wa * sa + q.wT * st;
+  if (q.has_goal) cost += q.wp * sp + q.term * q.wp * sterm;
+  f[b] = cost;
+}
+
+// ------------------------------------------------------------------------------------------
+// a8: dynamics equality residuals (planner.py:426-462)
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void dynamics_residual_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X,
+                                         const R* __restrict__ p0, const R* __restrict__ v0, R* __restrict__ Rout) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N, N3 = 3 * q.N;
+  for (int a = 0; a < 3; ++a) {
+    const R grav = (a == 2) ? q.grav : (R)0;
+    R pk = X[(size_t)a * ld + b];
+    R vk = X[(size_t)(N3 + a) * ld + b];
+    Rout[(size_t)a * ld + b] = pk - p0[(size_t)a * ld + b];            // planner.py:439
+    Rout[(size_t)(3 + a) * ld + b] = vk - v0[(size_t)a * ld + b];      // planner.py:440
+    for (int k = 0; k + 1 < N; ++k) {
+      const R tk = X[(size_t)(2 * N3 + 3 * k + a) * ld + b];
+      const R pn = X[(size_t)(3 * (k + 1) + a) * ld + b];
+      const R vn = X[(size_t)(N3 + 3 * (k + 1) + a) * ld + b];
+      const R acc = tk / q.mass - grav;                                // planner.py:445-447
+      Rout[(size_t)(6 + 6 * k + a) * ld + b] = pn - pk - vk * q.dt - (R)0.5 * acc * (q.dt * q.dt);   // :450-455
+      Rout[(size_t)(6 + 6 * k + 3 + a) * ld + b] = vn - vk - acc * q.dt;                             // :459
+      pk = pn; vk = vn;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a9: sphere-obstacle inequality residuals (planner.py:499-514); sphere table staged in LDS
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void obstacle_residual_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X,
+                                         const R* __restrict__ spheres, int K, R* __restrict__ C,
+                                         R* __restrict__ cmin, R* __restrict__ viol) {
+  __shared__ R sph[SE3MPC_MAX_SPHERES * 4];   // (cx, cy, cz, (r + margin)^2)
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    sph[4 * i + 0] = spheres[4 * i + 0];
+    sph[4 * i + 1] = spheres[4 * i + 1];
+    sph[4 * i + 2] = spheres[4 * i + 2];
+    const R s = spheres[4 * i + 3] + q.margin;              // planner.py:509
+    sph[4 * i + 3] = s * s;
+  }
+  __syncthreads();
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N;
+  R mn = INFINITY, vs = 0;
+  for (int k = 0; k < N; ++k) {
+    const R px = X[(size_t)(3 * k + 0) * ld + b];
+    const R py = X[(size_t)(3 * k + 1) * ld + b];
+    const R pz = X[(size_t)(3 * k + 2) * ld + b];
+    for (int j = 0; j < K; ++j) {
+      const R dx = px - sph[4 * j + 0], dy = py - sph[4 * j + 1], dz = pz - sph[4 * j + 2];
+      const R c = (dx * dx + dy * dy + dz * dz) - sph[4 * j + 3];     // planner.py:508-512
+      if (C != nullptr) C[(size_t)(k * K + j) * ld + b] = c;
+      mn = fmin(mn, c);
+      vs += fmax((R)0, -c);
+    }
+  }
+  if (cmin != nullptr) cmin[b] = mn;
+  if (viol != nullptr) viol[b] = vs;
+}
+
+// ------------------------------------------------------------------------------------------
+// a10: physical feasibility constraints (planner.py:472-497)
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void physical_constraints_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, R* __restrict__ C) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N, N3 = 3 * q.N;
+  for (int k = 0; k < N; ++k) {
+    R v2 = 0, a2 = 0, t2 = 0;
+    for (int a = 0; a < 3; ++a) {
+      const R v = X[(size_t)(N3 + 3 * k + a) * ld + b];
+      const R t = X[(size_t)(2 * N3 + 3 * k + a) * ld + b];
+      const R acc = t / q.mass - ((a == 2) ? q.grav : (R)0);
+      v2 += v * v; a2 += acc * acc; t2 += t * t;
+    }
+    C[(size_t)k * ld + b] = q.v_max2 - v2;                             // planner.py:479-481
+    C[(size_t)(N + k) * ld + b] = q.a_max2 - a2;                       // planner.py:484-489
+    C[(size_t)(2 * N + 2 * k) * ld + b] = q.t_max2 - t2;               // planner.py:494
+    C[(size_t)(2 * N + 2 * k + 1) * ld + b] = t2 - q.t_min2;           // planner.py:495
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// a11 + a12: accelerations, thrust magnitudes, attitudes and body rates (planner.py:582-654)
+// ------------------------------------------------------------------------------------------
+// One step of planner.py:616-653 for one lane.  prev (b1,b2,b3 of the last valid R) lives in
+// registers across the k loop; rows with |T| <= 1e-6 leave it untouched (planner.py:651-653).
+template <typename R>
+struct AttitudeState {
+  R b1[3], b2[3], b3[3];
+  bool valid;
+};
+
+template <typename R>
+__device__ __forceinline__ void attitude_step(const R t[3], R inv_dt, AttitudeState<R>& prev, R att[3], R rate[3], R& mag) {
+  mag = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);                 // planner.py:618
+  att[0] = att[1] = att[2] = (R)0;
+  rate[0] = rate[1] = rate[2] = (R)0;
+  if (!(mag > (R)1e-6)) return;                                        // planner.py:619, :651-653
+  R b3[3] = {t[0] / mag, t[1] / mag, t[2] / mag};                      // planner.py:621
+  // b1 = (1,0,0) x b3 = (0, -b3z, b3y)                                // planner.py:625-626
+  R b1[3] = {(R)0, -b3[2], b3[1]};
+  const R n1 = sqrt(b1[1] * b1[1] + b1[2] * b1[2]);                    // planner.py:627
+  if (n1 > (R)1e-6) { b1[1] /= n1; b1[2] /= n1; }                      // planner.py:628-629
+  else { b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0; }                   // planner.py:630-631
+  const R b2[3] = {b3[1] * b1[2] - b3[2] * b1[1],                      // planner.py:632
+                   b3[2] * b1[0] - b3[0] * b1[2],
+                   b3[0] * b1[1] - b3[1] * b1[0]};
+  // R = [b1 b2 b3] (columns).  roll = atan2(R21, R22), pitch = asin(-R20), yaw = atan2(R10, R00)
+  att[0] = atan2(b2[2], b3[2]);                                        // planner.py:636
+  att[1] = asin(fmin(fmax(-b1[2], (R)-1), (R)1));                      // planner.py:637 (clamped: rounding can leave |R20| 1 ulp above 1)
+  att[2] = atan2(b1[1], b1[0]);                                        // planner.py:638
+  if (prev.valid) {                                                    // planner.py:641-649
+    // omega = R^T (R - R_prev)/dt ; rates = (omega[2][1], omega[0][2], omega[1][0])
+    R d1[3], d2[3], d3[3];
+    for (int i = 0; i < 3; ++i) {
+      d1[i] = (b1[i] - prev.b1[i]) * inv_dt;
+      d2[i] = (b2[i] - prev.b2[i]) * inv_dt;
+      d3[i] = (b3[i] - prev.b3[i]) * inv_dt;
+    }
+    rate[0] = b3[0] * d2[0] + b3[1] * d2[1] + b3[2] * d2[2];
+    rate[1] = b1[0] * d3[0] + b1[1] * d3[1] + b1[2] * d3[2];
+    rate[2] = b2[0] * d1[0] + b2[1] * d1[1] + b2[2] * d1[2];
+  }
+  for (int i = 0; i < 3; ++i) { prev.b1[i] = b1[i]; prev.b2[i] = b2[i]; prev.b3[i] = b3[i]; }
+  prev.valid = true;                                                   // planner.py:650
+}
+
+template <typename R>
+__global__ void extract_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ T, R* __restrict__ acc,
+                               R* __restrict__ att, R* __restrict__ rates, R* __restrict__ thrust) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N;
+  AttitudeState<R> prev;
+  prev.valid = false;
+  for (int i = 0; i < 3; ++i) prev.b1[i] = prev.b2[i] = prev.b3[i] = (R)0;
+  for (int k = 0; k < N; ++k) {
+    R t[3];
+    for (int a = 0; a < 3; ++a) t[a] = T[(size_t)(3 * k + a) * ld + b];
+    R at[3], rt[3], mag;
+    attitude_step<R>(t, q.inv_dt, prev, at, rt, mag);
+    for (int a = 0; a < 3; ++a) {
+      const size_t r = (size_t)(3 * k + a) * ld + b;
+      if (acc != nullptr) acc[r] = t[a] / q.mass - ((a == 2) ? q.grav : (R)0);   // planner.py:589
+      if (att != nullptr) att[r] = at[a];
+      if (rates != nullptr) rates[r] = rt[a];
+    }
+    if (thrust != nullptr) thrust[(size_t)k * ld + b] = mag;                      // planner.py:601
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Shooting form: forward rollout (the recurrence of planner.py:449-460), objective of
+// planner.py:516-550 on the rolled-out states, exact gradient wrt T by the reverse sweep.
+// The three axes are independent double integrators and the cost is separable in them, so a
+// lane processes one axis at a time: only one axis' T_k, P_k, V_k are live.
+//
+// Three variants of the same arithmetic (selected by se3mpc_set_rollout_variant, default
+// chosen from measurements):
+//   REG  exact-N register arrays (t[N], ps[N], vs[N]); instantiated for the BASELINE horizons.
+//   LDS  any N: per-step state tiles P_k,V_k staged in LDS as [k][lane] (bank = lane, conflict
+//        free), re-read by the reverse sweep; T_k re-read from L1/L2.
+//   REV  any N: O(1) registers; the reverse sweep re-reads T_k (L2) and inverts the recurrence
+//        (V_k = V_{k+1} - a_k dt, P_k = P_{k+1} - V_k dt - a_k dt^2/2) instead of storing states.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t orderable_bits(float c) {
+  const uint32_t u = __float_as_uint(c);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// Epilogue shared by the three variants: store the cost and, if `key` is given, fold the
+// wavefront's best (cost, index) into *key -- a DPP min over the 64 lanes (wavefront-shuffle
+// reduction, no LDS), then ONE 64-bit atomic per wavefront.  Tail lanes (b >= B) stay active up
+// to here so the cross-lane ops see all 64 lanes; they contribute the identity.
+template <typename R>
+__device__ __forceinline__ void rollout_epilogue(bool live, int b, R c, R* __restrict__ cost,
+                                                 unsigned long long* __restrict__ key, uint32_t index_base) {
+  if (live) cost[b] = c;
+  if (key != nullptr) {
+    const uint32_t bits = live ? orderable_bits((float)c) : 0xFFFFFFFFu;
+    const uint32_t m = wave_min_u32(bits);
+    const int src = first_lane(wave_ballot(live && bits == m));
+    if (src >= 0 && lane_id() == src)
+      atomicMin(key, ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b));
+  }
+}
+
+template <typename R>
+struct RolloutSums {
+  R sp, sv, sa, st, sterm;
+};
+
+template <typename R>
+__device__ __forceinline__ R rollout_total(const DevParams<R>& q, const RolloutSums<R>& s) {
+  R c = q.wv * s.sv + q.wa * s.sa + q.wT * s.st;
+  if (q.has_goal) c += q.wp * s.sp + q.term * q.wp * s.sterm;
+  return c;
+}
+
+template <typename R, int N, bool GRAD, bool STATES>
+__global__ void __launch_bounds__(64)
+rollout_reg_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+                   const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
+                   R* __restrict__ gradT, R* __restrict__ Pout, R* __restrict__ Vout,
+                   unsigned long long* __restrict__ key, uint32_t index_base) {
+  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;                         // tail lanes shadow the last trajectory (loads only)
+  RolloutSums<R> s = {0, 0, 0, 0, 0};
+  const R two_wp = q.has_goal ? (R)2 * q.wp : (R)0;
+  const size_t stride = (size_t)3 * ld;
+#pragma unroll 1
+  for (int a = 0; a < 3; ++a) {
+    R t[N], ps[N], vs[N];
+    const R* tp = T + (size_t)a * ld + b;
+#pragma unroll
+    for (int k = 0; k < N; ++k) { t[k] = *tp; tp += stride; }
+    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
+    const R grav = (a == 2) ? q.grav : (R)0;
+    const R hov = (a == 2) ? q.hover : (R)0;
+    R p = p0[(size_t)a * ld + b];
+    R v = v0[(size_t)a * ld + b];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      ps[k] = p; vs[k] = v;
+      const R acc = t[k] * q.inv_mass - grav;
+      const R e = p - gl;
+      const R dev = t[k] - hov;
+      s.sp += e * e; s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      if (k == N - 1) s.sterm += e * e;
+      p = p + v * q.dt + q.half_dt2 * acc;                 // planner.py:450-455 solved for P_{k+1}
+      v = v + acc * q.dt;                                  // planner.py:459 solved for V_{k+1}
+    }
+    if (STATES) {
+      R* pp = Pout + (size_t)a * ld + b;
+      R* vp = Vout + (size_t)a * ld + b;
+#pragma unroll
+      for (int k = 0; k < N; ++k) { if (live) { *pp = ps[k]; *vp = vs[k]; } pp += stride; vp += stride; }
+    }
+    if (GRAD) {
+      R lamP = two_wp * ((R)1 + q.term) * (ps[N - 1] - gl);
+      R lamV = (R)2 * q.wv * vs[N - 1];
+      R* gp = gradT + (size_t)a * ld + b + (size_t)(N - 1) * stride;
+      if (live) *gp = (R)2 * q.wa * (t[N - 1] * q.inv_mass - grav) * q.inv_mass + (R)2 * q.wT * (t[N - 1] - hov);
+#pragma unroll
+      for (int k = N - 2; k >= 0; --k) {
+        gp -= stride;
+        const R acc = t[k] * q.inv_mass - grav;
+        if (live) *gp = (R)2 * q.wa * acc * q.inv_mass + (R)2 * q.wT * (t[k] - hov) + (q.half_dt2 * lamP + q.dt * lamV) * q.inv_mass;
+        lamV = (R)2 * q.wv * vs[k] + q.dt * lamP + lamV;
+        lamP = two_wp * (ps[k] - gl) + lamP;
+      }
+    }
+  }
+  rollout_epilogue<R>(live, b, rollout_total(q, s), cost, key, index_base);
+}
+
+template <typename R, bool GRAD, bool STATES>
+__global__ void __launch_bounds__(64)
+rollout_lds_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+                   const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
+                   R* __restrict__ gradT, R* __restrict__ Pout, R* __restrict__ Vout,
+                   unsigned long long* __restrict__ key, uint32_t index_base) {
+  HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  R* tile = reinterpret_cast<R*>(lds_raw);                 // [2N][64]: P_k at row 2k, V_k at row 2k+1
+  const int lane = threadIdx.x;                            // no barrier below: a wave only reads its own column
+  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;
+  const int N = q.N;
+  RolloutSums<R> s = {0, 0, 0, 0, 0};
+  const R two_wp = q.has_goal ? (R)2 * q.wp : (R)0;
+  const size_t stride = (size_t)3 * ld;
+#pragma unroll 1
+  for (int a = 0; a < 3; ++a) {
+    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
+    const R grav = (a == 2) ? q.grav : (R)0;
+    const R hov = (a == 2) ? q.hover : (R)0;
+    R p = p0[(size_t)a * ld + b];
+    R v = v0[(size_t)a * ld + b];
+    const R* tp = T + (size_t)a * ld + b;
+    R* pp = STATES ? Pout + (size_t)a * ld + b : nullptr;
+    R* vp = STATES ? Vout + (size_t)a * ld + b : nullptr;
+    R tk = (R)0;
+#pragma unroll 4
+    for (int k = 0; k < N; ++k) {
+      tk = *tp; tp += stride;
+      tile[(2 * k) * kWave + lane] = p;
+      tile[(2 * k + 1) * kWave + lane] = v;
+      if (STATES) { if (live) { *pp = p; *vp = v; } pp += stride; vp += stride; }
+      const R acc = tk * q.inv_mass - grav;
+      const R e = p - gl;
+      const R dev = tk - hov;
+      s.sp += e * e; s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      if (k == N - 1) s.sterm += e * e;
+      p = p + v * q.dt + q.half_dt2 * acc;
+      v = v + acc * q.dt;
+    }
+    if (GRAD) {
+      const R pl = tile[(2 * (N - 1)) * kWave + lane], vl = tile[(2 * (N - 1) + 1) * kWave + lane];
+      R lamP = two_wp * ((R)1 + q.term) * (pl - gl);
+      R lamV = (R)2 * q.wv * vl;
+      R* gp = gradT + (size_t)a * ld + b + (size_t)(N - 1) * stride;
+      if (live) *gp = (R)2 * q.wa * (tk * q.inv_mass - grav) * q.inv_mass + (R)2 * q.wT * (tk - hov);
+      tp -= stride;                                         // tp -> row N-1
+#pragma unroll 4
+      for (int k = N - 2; k >= 0; --k) {
+        gp -= stride; tp -= stride;
+        const R t = *tp;
+        const R pk = tile[(2 * k) * kWave + lane], vk = tile[(2 * k + 1) * kWave + lane];
+        const R acc = t * q.inv_mass - grav;
+        if (live) *gp = (R)2 * q.wa * acc * q.inv_mass + (R)2 * q.wT * (t - hov) + (q.half_dt2 * lamP + q.dt * lamV) * q.inv_mass;
+        lamV = (R)2 * q.wv * vk + q.dt * lamP + lamV;
+        lamP = two_wp * (pk - gl) + lamP;
+      }
+    }
+  }
+  rollout_epilogue<R>(live, b, rollout_total(q, s), cost, key, index_base);
+}
+
+template <typename R, bool GRAD, bool STATES>
+__global__ void __launch_bounds__(64)
+rollout_rev_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+                   const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
+                   R* __restrict__ gradT, R* __restrict__ Pout, R* __restrict__ Vout,
+                   unsigned long long* __restrict__ key, uint32_t index_base) {
+  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;
+  const int N = q.N;
+  RolloutSums<R> s = {0, 0, 0, 0, 0};
+  const R two_wp = q.has_goal ? (R)2 * q.wp : (R)0;
+  const size_t stride = (size_t)3 * ld;
+#pragma unroll 1
+  for (int a = 0; a < 3; ++a) {
+    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
+    const R grav = (a == 2) ? q.grav : (R)0;
+    const R hov = (a == 2) ? q.hover : (R)0;
+    R p = p0[(size_t)a * ld + b];
+    R v = v0[(size_t)a * ld + b];
+    const R* tp = T + (size_t)a * ld + b;
+    R* pp = STATES ? Pout + (size_t)a * ld + b : nullptr;
+    R* vp = STATES ? Vout + (size_t)a * ld + b : nullptr;
+    R tk = (R)0, pl = p, vl = v;
+#pragma unroll 4
+    for (int k = 0; k < N; ++k) {
+      tk = *tp; tp += stride;
+      if (STATES) { if (live) { *pp = p; *vp = v; } pp += stride; vp += stride; }
+      const R acc = tk * q.inv_mass - grav;
+      const R e = p - gl;
+      const R dev = tk - hov;
+      s.sp += e * e; s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      if (k == N - 1) s.sterm += e * e;
+      pl = p; vl = v;                                       // state at step k (P_{N-1}, V_{N-1} after the loop)
+      p = p + v * q.dt + q.half_dt2 * acc;
+      v = v + acc * q.dt;
+    }
+    if (GRAD) {
+      R lamP = two_wp * ((R)1 + q.term) * (pl - gl);
+      R lamV = (R)2 * q.wv * vl;
+      R* gp = gradT + (size_t)a * ld + b + (size_t)(N - 1) * stride;
+      if (live) *gp = (R)2 * q.wa * (tk * q.inv_mass - grav) * q.inv_mass + (R)2 * q.wT * (tk - hov);
+      tp -= stride;
+      R pk = pl, vk = vl;                                   // walk the states backwards
+#pragma unroll 4
+      for (int k = N - 2; k >= 0; --k) {
+        gp -= stride; tp -= stride;
+        const R t = *tp;
+        const R acc = t * q.inv_mass - grav;
+        vk = vk - acc * q.dt;                               // V_k from V_{k+1}
+        pk = pk - vk * q.dt - q.half_dt2 * acc;             // P_k from P_{k+1}
+        if (live) *gp = (R)2 * q.wa * acc * q.inv_mass + (R)2 * q.wT * (t - hov) + (q.half_dt2 * lamP + q.dt * lamV) * q.inv_mass;
+        lamV = (R)2 * q.wv * vk + q.dt * lamP + lamV;
+        lamP = two_wp * (pk - gl) + lamP;
+      }
+    }
+  }
+  rollout_epilogue<R>(live, b, rollout_total(q, s), cost, key, index_base);
+}
+
+// ------------------------------------------------------------------------------------------
+// a16: is_plan_valid (planner.py:717-737)
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void is_plan_valid_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ P, const R* __restrict__ V,
+                                     int32_t* __restrict__ valid) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const int N = q.N;
+  bool ok = true;
+  for (int k = 0; k < N; ++k) {
+    for (int a = 0; a < 3; ++a) {
+      const R x = P[(size_t)(3 * k + a) * ld + b];
+      if (isnan(x) || isinf(x)) ok = false;                            // planner.py:724
+      if (a == 2 && x < (R)0.1) ok = false;                            // planner.py:728
+      if (V != nullptr) {
+        const R v = V[(size_t)(3 * k + a) * ld + b];
+        if (fabs(v) > (R)20.0) ok = false;                             // planner.py:734
+      }
+    }
+  }
+  valid[b] = ok ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch argmin -> packed 64-bit key (orderable cost bits << 32 | global index)
+// ------------------------------------------------------------------------------------------
+
+template <typename R>
+__global__ void __launch_bounds__(256)
+argmin_kernel(int B, const R* __restrict__ cost, uint32_t index_base, unsigned long long* __restrict__ key) {
+  __shared__ unsigned long long wave_min[4];
+  unsigned long long best = ~0ull;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const unsigned long long k = ((unsigned long long)orderable_bits((float)cost[b]) << 32) | (unsigned long long)(index_base + (uint32_t)b);
+    best = k < best ? k : best;
+  }
+  // wavefront shuffle reduction (64 lanes)
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(best, off, kWave);
+    best = o < best ? o : best;
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) wave_min[wave] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned long long m = wave_min[0];
+    for (int w = 1; w < (int)(blockDim.x / kWave); ++w) m = wave_min[w] < m ? wave_min[w] : m;
+    atomicMin(key, m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// [rows][ld_in] -> [cols][ld_out] transpose through a padded LDS tile
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256)
+transpose_kernel(int rows, int cols, const R* __restrict__ in, int ld_in, R* __restrict__ out, int ld_out) {
+  __shared__ R tile[64][65];
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    if (r < rows && c < cols) tile[i][tx] = in[(size_t)r * ld_in + c];
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (r < rows && c < cols) out[(size_t)c * ld_out + r] = tile[tx][i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side: validation + launch
+// ------------------------------------------------------------------------------------------
+static inline int check_lane_args(const se3mpc_params* p, int B, int ld) {
+  if (p == nullptr) return SE3MPC_ERR_NULL;
+  const int rc = check_params_impl(p);
+  if (rc != SE3MPC_OK) return rc;
+  if (B < 0 || ld < B) return SE3MPC_ERR_SHAPE;
+  return SE3MPC_OK;
+}
+
+constexpr int kLaneBlock = 64;   // one wavefront per workgroup: small batches still spread over CUs
+
+template <typename R>
+int init_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal, int project, R* X0,
+              void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!p0 || !v0 || !X0 || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(init_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                     make_dev_params<R>(*p), B, ld, p0, v0, goal, project, X0);
+  return launch_status("se3mpc_init");
+}
+
+template <typename R>
+int cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* goal, R* f, R* g, void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!X || !f || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(cost_grad_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                     make_dev_params<R>(*p), B, ld, X, goal, f, g);
+  return launch_status("se3mpc_cost_grad");
+}
+
+template <typename R>
+int dynamics_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* p0, const R* v0, R* Rout,
+                           void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!X || !p0 || !v0 || !Rout) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(dynamics_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
+                     (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, p0, v0, Rout);
+  return launch_status("se3mpc_dynamics_residual");
+}
+
+template <typename R>
+int obstacle_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* spheres, int K, R* C, R* cmin,
+                           R* viol, void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (K < 0 || K > SE3MPC_MAX_SPHERES) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!X || (K > 0 && !spheres)) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(obstacle_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
+                     (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, spheres, K, C, cmin, viol);
+  return launch_status("se3mpc_obstacle_residual");
+}
+
+template <typename R>
+int physical_constraints_impl(const se3mpc_params* p, int B, int ld, const R* X, R* C, void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!X || !C) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(physical_constraints_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
+                     (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, C);
+  return launch_status("se3mpc_physical_constraints");
+}
+
+template <typename R>
+int extract_impl(const se3mpc_params* p, int B, int ld, const R* T, R* acc, R* att, R* rates, R* thrust, void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!T) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(extract_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                     make_dev_params<R>(*p), B, ld, T, acc, att, rates, thrust);
+  return launch_status("se3mpc_extract");
+}
+
+static int g_rollout_variant = 0;   // 0 auto, 1 REG, 2 LDS, 3 REV
+
+template <typename R, bool GRAD, bool STATES>
+int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* p0, const R* v0, const R* goal,
+                   const R* T, R* cost, R* gradT, R* P, R* V, unsigned long long* key, uint32_t index_base,
+                   hipStream_t s) {
+  const DevParams<R> q = make_dev_params<R>(*p);
+  const dim3 grid(grid_for(B, kLaneBlock)), block(kLaneBlock);
+  const int N = p->horizon;
+  // f64 register arrays spill beyond N = 20 (2 VGPRs per value)
+  const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
+  if (variant == 0) variant = has_reg ? 1 : 3;
+  if (variant == 1 && !has_reg) variant = 3;
+  if (variant == 1) {
+#define SE3MPC_REG_CASE(NN)                                                                                         \
+  case NN:                                                                                                          \
+    hipLaunchKernelGGL((rollout_reg_kernel<R, NN, GRAD, STATES>), grid, block, 0, s, q, B, ld, p0, v0, goal, T, cost, \
+                       gradT, P, V, key, index_base);                                                               \
+    break;
+    switch (N) {
+      SE3MPC_REG_CASE(6)
+      SE3MPC_REG_CASE(20)
+      default:
+        if constexpr (sizeof(R) == 4) {
+          switch (N) {
+            SE3MPC_REG_CASE(30)
+            SE3MPC_REG_CASE(50)
+          }
+        }
+    }
+#undef SE3MPC_REG_CASE
+  } else if (variant == 2) {
+    const size_t lds = (size_t)2 * N * kWave * sizeof(R);
+    hipLaunchKernelGGL((rollout_lds_kernel<R, GRAD, STATES>), grid, block, lds, s, q, B, ld, p0, v0, goal, T, cost,
+                       gradT, P, V, key, index_base);
+  } else {
+    hipLaunchKernelGGL((rollout_rev_kernel<R, GRAD, STATES>), grid, block, 0, s, q, B, ld, p0, v0, goal, T, cost,
+                       gradT, P, V, key, index_base);
+  }
+  return launch_status("se3mpc_rollout_cost_grad");
+}
+
+template <typename R>
+int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal, const R* T,
+                           R* cost, R* gradT, R* P, R* V, uint64_t* key64, uint32_t index_base, void* stream) {
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!p0 || !v0 || !T || !cost || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  if ((P == nullptr) != (V == nullptr)) return SE3MPC_ERR_NULL;   // states come as a pair
+  hipStream_t s = (hipStream_t)stream;
+  const int var = g_rollout_variant;
+  const bool grad = gradT != nullptr, states = P != nullptr;
+  if (grad && states) return rollout_launch<R, true, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
+  if (grad) return rollout_launch<R, true, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
+  if (states) return rollout_launch<R, false, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
+  return rollout_launch<R, false, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
+}
+
+template <typename R>
+int is_plan_valid_impl(const se3mpc_params* p, int B, int ld, const R* P, const R* V, int32_t* valid, void* stream) {
+  int rc = check_lane_args(p, B, ld);
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!P || !valid) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(is_plan_valid_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                     make_dev_params<R>(*p), B, ld, P, V, valid);
+  return launch_status("se3mpc_is_plan_valid");
+}
+
+template <typename R>
+int argmin_impl(int B, const R* cost, uint32_t index_base, uint64_t* key, void* stream) {
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (!key) return SE3MPC_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(key, 0xFF, sizeof(uint64_t), s) != hipSuccess) return launch_status("se3mpc_argmin(memset)");
+  if (B == 0) return SE3MPC_OK;
+  if (!cost) return SE3MPC_ERR_NULL;
+  int grid = grid_for(B, 256);
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(argmin_kernel<R>, dim3(grid), dim3(256), 0, s, B, cost, index_base, (unsigned long long*)key);
+  return launch_status("se3mpc_argmin");
+}
+
+template <typename R>
+int transpose_impl(int rows, int cols, const R* in, int ld_in, R* out, int ld_out, void* stream) {
+  if (rows < 0 || cols < 0 || ld_in < cols || ld_out < rows) return SE3MPC_ERR_SHAPE;
+  if (rows == 0 || cols == 0) return SE3MPC_OK;
+  if (!in || !out) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(transpose_kernel<R>, dim3(grid_for(cols, 64), grid_for(rows, 64)), dim3(256), 0,
+                     (hipStream_t)stream, rows, cols, in, ld_in, out, ld_out);
+  return launch_status("se3mpc_transpose");
+}
+
+}  // namespace se3mpc
+
+// ------------------------------------------------------------------------------------------
+// C ABI (include/se3mpc.h)
+// ------------------------------------------------------------------------------------------
+using namespace se3mpc;
+
+#define SE3MPC_DEFINE_LANE_API(SUF, R)                                                                                  \
+  extern "C" int se3mpc_init_##SUF(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal,        \
+                                   int project, R* X0, void* stream) {                                                   \
+    return init_impl<R>(p, B, ld, p0, v0, goal, project, X0, stream);                                                    \
+  }                                                                                                                      \
+  extern "C" int se3mpc_cost_grad_##SUF(const se3mpc_params* p, int B, int ld, const R* X, const R* goal, R* f, R* g,     \
+                                        void* stream) {                                                                  \
+    return cost_grad_impl<R>(p, B, ld, X, goal, f, g, stream);                                                           \
+  }                                                                                                                      \
+  extern "C" int se3mpc_dynamics_residual_##SUF(const se3mpc_params* p, int B, int ld, const R* X, const R* p0,           \
+                                                const R* v0, R* Rout, void* stream) {                                    \
+    return dynamics_residual_impl<R>(p, B, ld, X, p0, v0, Rout, stream);                                                 \
+  }                                                                                                                      \
+  extern "C" int se3mpc_obstacle_residual_##SUF(const se3mpc_params* p, int B, int ld, const R* X, const R* spheres,      \
+                                                int K, R* C, R* cmin, R* viol, void* stream) {                           \
+    return obstacle_residual_impl<R>(p, B, ld, X, spheres, K, C, cmin, viol, stream);                                    \
+  }                                                                                                                      \
+  extern "C" int se3mpc_physical_constraints_##SUF(const se3mpc_params* p, int B, int ld, const R* X, R* C,               \
+                                                   void* stream) {                                                       \
+    return physical_constraints_impl<R>(p, B, ld, X, C, stream);                                                         \
+  }                                                                                                                      \
+  extern "C" int se3mpc_extract_##SUF(const se3mpc_params* p, int B, int ld, const R* T, R* acc, R* att, R* rates,        \
+                                      R* thrust, void* stream) {                                                         \
+    return extract_impl<R>(p, B, ld, T, acc, att, rates, thrust, stream);                                                \
+  }                                                                                                                      \
+  extern "C" int se3mpc_rollout_cost_grad_##SUF(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0,          \
+                                                const R* goal, const R* T, R* cost, R* gradT, R* P, R* V,                \
+                                                uint64_t* key, uint32_t index_base, void* stream) {                      \
+    return rollout_cost_grad_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, stream);             \
+  }                                                                                                                      \
+  extern "C" int se3mpc_is_plan_valid_##SUF(const se3mpc_params* p, int B, int ld, const R* P, const R* V,                \
+                                            int32_t* valid, void* stream) {                                              \
+    return is_plan_valid_impl<R>(p, B, ld, P, V, valid, stream);                                                         \
+  }                                                                                                                      \
+  extern "C" int se3mpc_argmin_##SUF(int B, const R* cost, uint32_t index_base, uint64_t* key, void* stream) {            \
+    return argmin_impl<R>(B, cost, index_base, key, stream);                                                             \
+  }                                                                                                                      \
+  extern "C" int se3mpc_transpose_##SUF(int rows, int cols, const R* in, int ld_in, R* out, int ld_out, void* stream) {   \
+    return transpose_impl<R>(rows, cols, in, ld_in, out, ld_out, stream);                                                \
+  }
+
+extern "C" int se3mpc_set_rollout_variant(int variant) {
+  if (variant < 0 || variant > 3) return SE3MPC_ERR_SHAPE;
+  se3mpc::g_rollout_variant = variant;
+  return SE3MPC_OK;
+}
+
+SE3MPC_DEFINE_LANE_API(f32, float)
+SE3MPC_DEFINE_LANE_API(f64, double)

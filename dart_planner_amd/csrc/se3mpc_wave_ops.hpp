@@ -1,0 +1,111 @@
+// se3mpc_wave_ops.hpp -- 64-lane wavefront reductions on CDNA4 with DPP (no LDS traffic).
+//
+// A reduction is 4 in-row butterfly steps (quad_perm xor1, xor2, row_half_mirror, row_mirror:
+// afterwards every lane of a 16-lane row holds the row result), then row_bcast:15 into rows 1,3
+// and row_bcast:31 into rows 2,3, after which lane 63 holds the wave result, which v_readlane
+// broadcasts through an SGPR.  64-bit values move as two 32-bit DPP movs per step.
+// (tests/emu shadows this header with a host implementation of the same functions.)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace se3mpc {
+
+constexpr int kDppQuadXor1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+constexpr int kDppRowBcast15 = 0x142;
+constexpr int kDppRowBcast31 = 0x143;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const uint64_t o = (uint64_t)__double_as_longlong(old), x = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)o, (uint32_t)x);
+  const uint32_t hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(o >> 32), (uint32_t)(x >> 32));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double readlane63_f64(double v) {
+  const uint64_t x = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, 63);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), 63);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+
+// Sum over the 64 lanes, result in every lane.  All 64 lanes must be active.
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_f64<kDppQuadXor1, 0xF>(0.0, v);
+  v += dpp_f64<kDppQuadXor2, 0xF>(0.0, v);
+  v += dpp_f64<kDppRowHalfMirror, 0xF>(0.0, v);
+  v += dpp_f64<kDppRowMirror, 0xF>(0.0, v);
+  v += dpp_f64<kDppRowBcast15, 0xA>(0.0, v);
+  v += dpp_f64<kDppRowBcast31, 0xC>(0.0, v);
+  return readlane63_f64(v);
+}
+
+__device__ __forceinline__ double wave_max(double v) {
+  const double ninf = -__builtin_huge_val();
+  v = fmax(v, dpp_f64<kDppQuadXor1, 0xF>(ninf, v));
+  v = fmax(v, dpp_f64<kDppQuadXor2, 0xF>(ninf, v));
+  v = fmax(v, dpp_f64<kDppRowHalfMirror, 0xF>(ninf, v));
+  v = fmax(v, dpp_f64<kDppRowMirror, 0xF>(ninf, v));
+  v = fmax(v, dpp_f64<kDppRowBcast15, 0xA>(ninf, v));
+  v = fmax(v, dpp_f64<kDppRowBcast31, 0xC>(ninf, v));
+  return readlane63_f64(v);
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+  const double pinf = __builtin_huge_val();
+  v = fmin(v, dpp_f64<kDppQuadXor1, 0xF>(pinf, v));
+  v = fmin(v, dpp_f64<kDppQuadXor2, 0xF>(pinf, v));
+  v = fmin(v, dpp_f64<kDppRowHalfMirror, 0xF>(pinf, v));
+  v = fmin(v, dpp_f64<kDppRowMirror, 0xF>(pinf, v));
+  v = fmin(v, dpp_f64<kDppRowBcast15, 0xA>(pinf, v));
+  v = fmin(v, dpp_f64<kDppRowBcast31, 0xC>(pinf, v));
+  return readlane63_f64(v);
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+  auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+  v = mn(v, dpp_u32<kDppQuadXor1, 0xF>(0xFFFFFFFFu, v));
+  v = mn(v, dpp_u32<kDppQuadXor2, 0xF>(0xFFFFFFFFu, v));
+  v = mn(v, dpp_u32<kDppRowHalfMirror, 0xF>(0xFFFFFFFFu, v));
+  v = mn(v, dpp_u32<kDppRowMirror, 0xF>(0xFFFFFFFFu, v));
+  v = mn(v, dpp_u32<kDppRowBcast15, 0xA>(0xFFFFFFFFu, v));
+  v = mn(v, dpp_u32<kDppRowBcast31, 0xC>(0xFFFFFFFFu, v));
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += (int)dpp_u32<kDppQuadXor1, 0xF>(0u, (uint32_t)v);
+  v += (int)dpp_u32<kDppQuadXor2, 0xF>(0u, (uint32_t)v);
+  v += (int)dpp_u32<kDppRowHalfMirror, 0xF>(0u, (uint32_t)v);
+  v += (int)dpp_u32<kDppRowMirror, 0xF>(0u, (uint32_t)v);
+  v += (int)dpp_u32<kDppRowBcast15, 0xA>(0u, (uint32_t)v);
+  v += (int)dpp_u32<kDppRowBcast31, 0xC>(0u, (uint32_t)v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// 64-bit mask of lanes whose predicate is true (s_cmp -> SGPR pair), and its lowest set lane.
+__device__ __forceinline__ uint64_t wave_ballot(bool pred) { return __ballot(pred); }
+__device__ __forceinline__ int first_lane(uint64_t mask) { return mask ? __builtin_ctzll(mask) : -1; }
+
+// Value of lane `src` (wave-uniform src) in every lane.
+__device__ __forceinline__ double wave_bcast(double v, int src) {
+  const uint64_t x = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), src);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ float wave_bcast(float v, int src) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), src));
+}
+__device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+}  // namespace se3mpc

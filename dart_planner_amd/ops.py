@@ -1,0 +1,267 @@
+"""Array front-end of the C ABI: shapes, allocation and pointer hand-over.
+
+``Ops`` is written against a tiny array-backend protocol so that the *same* host logic serves
+PyTorch-ROCm tensors in production (:class:`TorchBackend`: CUDA tensors only, current HIP
+stream, libse3mpc.so) and plain host buffers in the CPU test-suite (``tests/emu``).  PyTorch is
+plumbing here -- device memory and streams -- every number is produced by the HIP kernels.
+
+Layouts (include/se3mpc.h): evaluation ops use the lane layout ``[row][b]`` (one trajectory per
+lane), the solver uses the problem layout ``[b][row]`` (the reference's decision-vector packing,
+src/dart_planner/planning/se3_mpc_planner.py:361-376).
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .capi import Library, Params, SolveInfo, get_library, SE3MPC_MAX_SPHERES
+
+INFO_DTYPE = np.dtype([("fun", "<f8"), ("nit", "<i4"), ("nfev", "<i4"), ("status", "<i4"), ("task", "<i4")])
+assert INFO_DTYPE.itemsize == 24
+
+
+class TorchBackend:
+    """PyTorch-ROCm tensors on a HIP device.  Refuses CPU tensors: there is no CPU path."""
+
+    def __init__(self, device=None):
+        import torch
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("dart_planner_amd needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._dt = {"f32": torch.float32, "f64": torch.float64, "i32": torch.int32, "i64": torch.int64,
+                    "u8": torch.uint8}
+
+    def empty(self, shape, kind):
+        return self.torch.empty(shape, dtype=self._dt[kind], device=self.device)
+
+    def suffix(self, a) -> str:
+        if a.dtype == self.torch.float32:
+            return "f32"
+        if a.dtype == self.torch.float64:
+            return "f64"
+        raise TypeError(f"se3mpc kernels compute in float32 or float64, got {a.dtype}")
+
+    def check(self, a, name: str):
+        if not self.torch.is_tensor(a) or not a.is_cuda:
+            raise TypeError(f"{name}: expected a CUDA (HIP) tensor; there is no CPU path")
+        if a.device != self.device:
+            raise ValueError(f"{name}: tensor on {a.device}, backend on {self.device}")
+        if not a.is_contiguous():
+            raise ValueError(f"{name}: tensor must be contiguous")
+        return a
+
+    def ptr(self, a) -> int:
+        return 0 if a is None else a.data_ptr()
+
+    def stream(self) -> int:
+        return self.torch.cuda.current_stream(self.device).cuda_stream
+
+    def to_host(self, a) -> np.ndarray:
+        return a.detach().cpu().numpy()
+
+
+class Ops:
+    """Shape-checked calls into libse3mpc for one array backend."""
+
+    def __init__(self, backend=None, library: Optional[Library] = None):
+        self.lib = library if library is not None else get_library()
+        self.be = backend if backend is not None else TorchBackend()
+
+    # ------------------------------------------------------------------ helpers
+    def _lane(self, a, rows: int, name: str):
+        self.be.check(a, name)
+        if a.ndim != 2 or a.shape[0] != rows:
+            raise ValueError(f"{name}: expected shape ({rows}, ld), got {tuple(a.shape)}")
+        return a
+
+    def _same(self, ref, *others):
+        suf = self.be.suffix(ref)
+        for o in others:
+            if o is not None and (self.be.suffix(o) != suf or o.shape[-1] != ref.shape[-1]):
+                raise ValueError("all lane-layout operands must share dtype and leading dimension")
+        return suf
+
+    @staticmethod
+    def _B(ld: int, B: Optional[int]) -> int:
+        B = ld if B is None else int(B)
+        if B < 0 or B > ld:
+            raise ValueError(f"B={B} outside [0, ld={ld}]")
+        return B
+
+    # ------------------------------------------------------------------ lane layout
+    def init(self, params: Params, p0, v0, goal, project: bool = False, B: Optional[int] = None):
+        """a3 (+a4 projection): -> X0 (9N, ld)."""
+        N = params.horizon
+        self._lane(p0, 3, "p0"); self._lane(v0, 3, "v0")
+        if params.has_goal:
+            self._lane(goal, 3, "goal")
+        suf = self._same(p0, v0, goal if params.has_goal else None)
+        ld = p0.shape[1]
+        X0 = self.be.empty((9 * N, ld), suf)
+        self.lib.call("init", suf, self._B(ld, B), ld, self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(goal if params.has_goal else None), int(bool(project)), self.be.ptr(X0),
+                      self.be.stream(), params=params)
+        return X0
+
+    def cost_grad(self, params: Params, X, goal, want_grad: bool = True, B: Optional[int] = None):
+        """a5 + a6: -> (f (ld,), g (9N, ld) | None)."""
+        N = params.horizon
+        self._lane(X, 9 * N, "X")
+        if params.has_goal:
+            self._lane(goal, 3, "goal")
+        suf = self._same(X, goal if params.has_goal else None)
+        ld = X.shape[1]
+        f = self.be.empty((ld,), suf)
+        g = self.be.empty((9 * N, ld), suf) if want_grad else None
+        self.lib.call("cost_grad", suf, self._B(ld, B), ld, self.be.ptr(X),
+                      self.be.ptr(goal if params.has_goal else None), self.be.ptr(f), self.be.ptr(g),
+                      self.be.stream(), params=params)
+        return f, g
+
+    def dynamics_residual(self, params: Params, X, p0, v0, B: Optional[int] = None):
+        """a8: -> R (6N, ld)."""
+        N = params.horizon
+        self._lane(X, 9 * N, "X"); self._lane(p0, 3, "p0"); self._lane(v0, 3, "v0")
+        suf = self._same(X, p0, v0)
+        ld = X.shape[1]
+        R = self.be.empty((6 * N, ld), suf)
+        self.lib.call("dynamics_residual", suf, self._B(ld, B), ld, self.be.ptr(X), self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(R), self.be.stream(), params=params)
+        return R
+
+    def obstacle_residual(self, params: Params, X, spheres, materialize: bool = True, reduce: bool = True,
+                          B: Optional[int] = None):
+        """a9: spheres (K, 4) = (cx, cy, cz, r) -> (C (N*K, ld) | None, cmin (ld,) | None, viol (ld,) | None)."""
+        N = params.horizon
+        self._lane(X, 9 * N, "X")
+        self.be.check(spheres, "spheres")
+        if spheres.ndim != 2 or spheres.shape[1] != 4 or spheres.shape[0] > SE3MPC_MAX_SPHERES:
+            raise ValueError(f"spheres: expected (K<={SE3MPC_MAX_SPHERES}, 4), got {tuple(spheres.shape)}")
+        suf = self.be.suffix(X)
+        if self.be.suffix(spheres) != suf:
+            raise ValueError("spheres dtype must match X")
+        K, ld = spheres.shape[0], X.shape[1]
+        Cm = self.be.empty((N * K, ld), suf) if materialize else None
+        cmin = self.be.empty((ld,), suf) if reduce else None
+        viol = self.be.empty((ld,), suf) if reduce else None
+        self.lib.call("obstacle_residual", suf, self._B(ld, B), ld, self.be.ptr(X), self.be.ptr(spheres), K,
+                      self.be.ptr(Cm), self.be.ptr(cmin), self.be.ptr(viol), self.be.stream(), params=params)
+        return Cm, cmin, viol
+
+    def physical_constraints(self, params: Params, X, B: Optional[int] = None):
+        """a10: -> C (4N, ld)."""
+        N = params.horizon
+        self._lane(X, 9 * N, "X")
+        suf, ld = self.be.suffix(X), X.shape[1]
+        Cm = self.be.empty((4 * N, ld), suf)
+        self.lib.call("physical_constraints", suf, self._B(ld, B), ld, self.be.ptr(X), self.be.ptr(Cm),
+                      self.be.stream(), params=params)
+        return Cm
+
+    def extract(self, params: Params, T, B: Optional[int] = None):
+        """a11 + a12 on the T block (3N, ld): -> acc, att, rates (3N, ld), thrust (N, ld)."""
+        N = params.horizon
+        self._lane(T, 3 * N, "T")
+        suf, ld = self.be.suffix(T), T.shape[1]
+        acc, att, rates = (self.be.empty((3 * N, ld), suf) for _ in range(3))
+        thrust = self.be.empty((N, ld), suf)
+        self.lib.call("extract", suf, self._B(ld, B), ld, self.be.ptr(T), self.be.ptr(acc), self.be.ptr(att),
+                      self.be.ptr(rates), self.be.ptr(thrust), self.be.stream(), params=params)
+        return acc, att, rates, thrust
+
+    def rollout_cost_grad(self, params: Params, p0, v0, goal, T, want_grad: bool = True, want_states: bool = False,
+                          B: Optional[int] = None, out=None, key=None, index_base: int = 0):
+        """Shooting-form rollout + cost (+ gradient wrt T, + rolled-out states).
+        -> (cost (ld,), gradT (3N, ld) | None, P (3N, ld) | None, V (3N, ld) | None).
+        ``out=(cost, gradT)`` reuses preallocated outputs (the benchmark's steady state).
+        ``key`` (int64 (1,), preset to -1 == UINT64_MAX by the caller) receives the fused batch
+        argmin: min over b of (orderable cost bits << 32 | index_base + b)."""
+        N = params.horizon
+        self._lane(p0, 3, "p0"); self._lane(v0, 3, "v0"); self._lane(T, 3 * N, "T")
+        if params.has_goal:
+            self._lane(goal, 3, "goal")
+        suf = self._same(T, p0, v0, goal if params.has_goal else None)
+        ld = T.shape[1]
+        if out is not None:
+            cost, gradT = out
+        else:
+            cost = self.be.empty((ld,), suf)
+            gradT = self.be.empty((3 * N, ld), suf) if want_grad else None
+        P = self.be.empty((3 * N, ld), suf) if want_states else None
+        V = self.be.empty((3 * N, ld), suf) if want_states else None
+        self.lib.call("rollout_cost_grad", suf, self._B(ld, B), ld, self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost),
+                      self.be.ptr(gradT), self.be.ptr(P), self.be.ptr(V), self.be.ptr(key), int(index_base),
+                      self.be.stream(), params=params)
+        return cost, gradT, P, V
+
+    def is_plan_valid(self, params: Params, P, V=None, B: Optional[int] = None):
+        """a16: -> int32 (ld,)."""
+        N = params.horizon
+        self._lane(P, 3 * N, "P")
+        if V is not None:
+            self._lane(V, 3 * N, "V")
+        suf = self._same(P, V)
+        ld = P.shape[1]
+        valid = self.be.empty((ld,), "i32")
+        self.lib.call("is_plan_valid", suf, self._B(ld, B), ld, self.be.ptr(P), self.be.ptr(V), self.be.ptr(valid),
+                      self.be.stream(), params=params)
+        return valid
+
+    def argmin(self, cost, index_base: int = 0, out=None):
+        """-> int64 (1,) holding the packed unsigned key (cost bits << 32 | index)."""
+        self.be.check(cost, "cost")
+        suf = self.be.suffix(cost)
+        key = out if out is not None else self.be.empty((1,), "i64")
+        self.lib.call("argmin", suf, int(cost.shape[0]), self.be.ptr(cost), int(index_base), self.be.ptr(key),
+                      self.be.stream())
+        return key
+
+    def decode_key(self, key) -> Tuple[int, float]:
+        k = int(self.be.to_host(key).reshape(-1)[0]) & 0xFFFFFFFFFFFFFFFF
+        return self.lib.key_index(k), self.lib.key_cost(k)
+
+    def transpose(self, a):
+        """(rows, cols) -> (cols, rows), through the LDS-tiled kernel."""
+        self.be.check(a, "a")
+        if a.ndim != 2:
+            raise ValueError("transpose: 2-D only")
+        suf = self.be.suffix(a)
+        rows, cols = a.shape
+        out = self.be.empty((cols, rows), suf)
+        self.lib.call("transpose", suf, rows, cols, self.be.ptr(a), cols, self.be.ptr(out), rows, self.be.stream())
+        return out
+
+    # ------------------------------------------------------------------ problem layout
+    def solve(self, params: Params, p0, v0, goal, x0=None, want_trajectory: bool = True):
+        """a7 (+a3, a4, a11, a12): batched L-BFGS-B solve, one wavefront per problem.
+        p0, v0, goal: (B, 3);  x0: (B, 9N) or None (reference cold start).
+        -> dict(x (B,9N), info (device bytes), acc/att/rates (B,N,3), thrust (B,N))."""
+        N = params.horizon
+        for a, nm in ((p0, "p0"), (v0, "v0")) + (((goal, "goal"),) if params.has_goal else ()):
+            self.be.check(a, nm)
+            if a.ndim != 2 or a.shape[1] != 3 or a.shape[0] != p0.shape[0]:
+                raise ValueError(f"{nm}: expected (B, 3), got {tuple(a.shape)}")
+        suf = self.be.suffix(p0)
+        B = p0.shape[0]
+        if x0 is not None:
+            self.be.check(x0, "x0")
+            if tuple(x0.shape) != (B, 9 * N) or self.be.suffix(x0) != suf:
+                raise ValueError(f"x0: expected ({B}, {9 * N}) {suf}")
+        X = self.be.empty((B, 9 * N), suf)
+        info = self.be.empty((B * INFO_DTYPE.itemsize,), "u8")
+        acc = att = rates = thrust = None
+        if want_trajectory:
+            acc, att, rates = (self.be.empty((B, N, 3), suf) for _ in range(3))
+            thrust = self.be.empty((B, N), suf)
+        self.lib.call("solve", suf, B, self.be.ptr(p0), self.be.ptr(v0), self.be.ptr(goal if params.has_goal else None),
+                      self.be.ptr(x0), self.be.ptr(X), self.be.ptr(info), self.be.ptr(acc), self.be.ptr(att),
+                      self.be.ptr(rates), self.be.ptr(thrust), self.be.stream(), params=params)
+        return dict(x=X, info=info, accelerations=acc, attitudes=att, body_rates=rates, thrusts=thrust)
+
+    def info_to_host(self, info) -> np.ndarray:
+        """Device bytes of se3mpc_solve_info[B] -> NumPy structured array (synchronises)."""
+        return np.frombuffer(self.be.to_host(info).tobytes(), dtype=INFO_DTYPE)

@@ -1,0 +1,224 @@
+/*
+ * se3mpc.h -- C ABI of libse3mpc.so, the MI355X (gfx950) SE(3) MPC inner solver.
+ *
+ * Drop-in boundary for the hot path of DART-Planner's SE3MPCPlanner
+ * (reference: src/dart_planner/planning/se3_mpc_planner.py, "planner.py" below).  The
+ * reference has no FFI of its own (it is pure Python on NumPy/SciPy); these entry points are
+ * what a ctypes binding inside that file would call instead of its NumPy/SciPy arithmetic.
+ * INTEGRATION.md shows that binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns an
+ *     int status (SE3MPC_OK == 0, negative = error); nothing throws across the ABI.
+ *   - All data pointers are DEVICE pointers (HBM) owned by the caller; the library never
+ *     allocates or frees device memory and never synchronises the stream (graph-capturable).
+ *     `stream` is a hipStream_t passed as void* (NULL = the default stream).
+ *   - Two arithmetic types per entry point: `_f32` (production) and `_f64` (the tolerance
+ *     check of BASELINE.json config 5).  Parameters are always doubles on the host side.
+ *   - Two data layouts:
+ *       "lane layout"  (evaluation kernels): row-major [row][b], b fastest, leading dimension
+ *         `ld` >= B elements -- one trajectory per lane, every (row) access of a wavefront is
+ *         one coalesced 256-B line.  Rows of a decision vector follow the reference packing
+ *         (planner.py:361-376): P block rows 3k+a, V block rows 3N+3k+a, T block rows
+ *         6N+3k+a (k = step, a = axis).
+ *       "problem layout" (solver): [b][row], row fastest -- the reference's own packing of one
+ *         decision vector per problem; one 64-lane wavefront owns one problem.
+ *     se3mpc_transpose_* converts between the two.
+ *   - B == 0 is legal everywhere and is a no-op.  1 <= horizon <= SE3MPC_MAX_HORIZON.
+ */
+#ifndef SE3MPC_H
+#define SE3MPC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE3MPC_ABI_VERSION 1
+#define SE3MPC_MAX_HORIZON 64      /* 9*N <= 576 decision variables per problem            */
+#define SE3MPC_MAX_CORRECTIONS 10  /* L-BFGS memory m (SciPy default maxcor = 10)          */
+#define SE3MPC_MAX_SPHERES 256     /* obstacle table staged in LDS (4 KB)                  */
+
+enum se3mpc_status {
+  SE3MPC_OK = 0,
+  SE3MPC_ERR_NULL = -1,        /* a required pointer is NULL                               */
+  SE3MPC_ERR_HORIZON = -2,     /* horizon outside [1, SE3MPC_MAX_HORIZON]                  */
+  SE3MPC_ERR_SHAPE = -3,       /* B < 0, ld < B, K out of range, ...                       */
+  SE3MPC_ERR_PARAM = -4,       /* non-finite / non-positive mass, dt, ...                  */
+  SE3MPC_ERR_WORKSPACE = -5,   /* workspace too small                                      */
+  SE3MPC_ERR_LAUNCH = -6,      /* HIP reported a launch error (see se3mpc_last_error)      */
+  SE3MPC_ERR_NO_DEVICE = -7    /* no gfx950 device visible                                 */
+};
+
+/* SE3MPCConfig (planner.py:36-79) + constructor constants (planner.py:149-151), unit-stripped
+ * to SI magnitudes.  se3mpc_default_params() fills the reference defaults. */
+typedef struct se3mpc_params {
+  int32_t horizon;              /* prediction_horizon N            (planner.py:41, default 6) */
+  int32_t has_goal;             /* 0: goal_position is None -> goal terms skipped (:524,:546,:567) */
+  double dt;                    /* planner.py:99-105 (timing manager: 1/400 s)                */
+  double mass;                  /* 1.5 kg  (planner.py:149)                                   */
+  double gravity;               /* 9.81    (planner.py:150)                                   */
+  double position_weight;       /* 100     (planner.py:56)                                    */
+  double velocity_weight;       /* 10      (planner.py:57)                                    */
+  double acceleration_weight;   /* 1       (planner.py:58)                                    */
+  double thrust_weight;         /* 0.1     (planner.py:59)                                    */
+  double terminal_factor;       /* 10      (planner.py:548)                                   */
+  double position_bound;        /* 100 m   (planner.py:384)                                   */
+  double max_velocity;          /* 10 m/s  (planner.py:45, :388)                              */
+  double max_acceleration;      /* 15      (planner.py:46, :489)                              */
+  double max_thrust;            /* 25 N    (planner.py:48)                                    */
+  double min_thrust;            /* 2 N     (planner.py:49)                                    */
+  double max_tilt_angle;        /* pi/4    (planner.py:52, :393)                              */
+  double safety_margin;         /* 1.5 m   (planner.py:64, :509)                              */
+  /* scipy.optimize.minimize(method="L-BFGS-B") options as the reference sets them (:256-268) */
+  int32_t max_iterations;       /* maxiter = 15 (planner.py:67)                               */
+  int32_t max_corrections;      /* maxcor  = 10 (SciPy default)                               */
+  int32_t max_linesearch;       /* maxls   = 20 (SciPy default)                               */
+  int32_t max_fun;              /* maxfun  = 15000 (SciPy default)                            */
+  double pgtol;                 /* gtol = convergence_tolerance = 0.05 (planner.py:264)       */
+  double ftol;                  /* ftol = 10*convergence_tolerance = 0.5 (planner.py:265)     */
+} se3mpc_params;
+
+/* Per-problem result of the solver, mirroring scipy's OptimizeResult fields the reference
+ * reads (planner.py:271-278): status 0 = converged, 1 = iteration/evaluation limit,
+ * 2 = abnormal termination in line search.  `task` is the L-BFGS-B stop reason. */
+typedef struct se3mpc_solve_info {
+  double fun;        /* f at the returned x                                              */
+  int32_t nit;       /* iterations                                                       */
+  int32_t nfev;      /* objective/gradient evaluations                                   */
+  int32_t status;    /* scipy status: 0, 1 or 2                                          */
+  int32_t task;      /* enum se3mpc_task                                                 */
+} se3mpc_solve_info;
+
+enum se3mpc_task {
+  SE3MPC_TASK_CONV_PGTOL = 1,    /* CONVERGENCE: NORM OF PROJECTED GRADIENT <= PGTOL      */
+  SE3MPC_TASK_CONV_FTOL = 2,     /* CONVERGENCE: REL_REDUCTION_OF_F <= FACTR*EPSMCH       */
+  SE3MPC_TASK_STOP_MAXITER = 3,  /* STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT           */
+  SE3MPC_TASK_STOP_MAXFUN = 4,   /* STOP: TOTAL NO. OF F,G EVALUATIONS EXCEEDS LIMIT      */
+  SE3MPC_TASK_ABNORMAL = 5       /* ABNORMAL TERMINATION IN LNSRCH                        */
+};
+
+/* ------------------------------------------------------------------ library / params */
+int se3mpc_abi_version(void);
+/* 0-terminated message of the last failing HIP call on this thread ("" if none). */
+const char* se3mpc_last_error(void);
+/* Number of visible gfx950 devices (0 if none / HIP not usable); never fails. */
+int se3mpc_device_count(void);
+/* Reference defaults (planner.py:36-79, :149-151); horizon 6, dt 1/400, has_goal 1. */
+int se3mpc_default_params(se3mpc_params* out);
+/* SE3MPC_OK or the error a kernel entry point would return for these params. */
+int se3mpc_check_params(const se3mpc_params* p);
+
+/* ------------------------------------------------------------------ lane layout: [row][b]
+ * Common arguments: B trajectories, leading dimension ld (elements), device pointers.
+ * p0, v0, goal: [3][ld].   X: [9N][ld].   T: [3N][ld].
+ */
+
+/* Cold start, replaces _create_straight_line_initialization (planner.py:329-359); with
+ * project != 0 also clips into the box of _setup_optimization_bounds (planner.py:378-402),
+ * which is what L-BFGS-B does to x0 before its first evaluation.  X0: [9N][ld]. */
+int se3mpc_init_f32(const se3mpc_params* p, int B, int ld, const float* p0, const float* v0,
+                    const float* goal, int project, float* X0, void* stream);
+int se3mpc_init_f64(const se3mpc_params* p, int B, int ld, const double* p0, const double* v0,
+                    const double* goal, int project, double* X0, void* stream);
+
+/* Objective and the reference's gradient on the full decision vector, replaces
+ * _objective_function (planner.py:516-550) and _objective_gradient (planner.py:552-580,
+ * reproduced as is -- it is not the derivative of the objective).  f: [B]; g: [9N][ld] or NULL. */
+int se3mpc_cost_grad_f32(const se3mpc_params* p, int B, int ld, const float* X, const float* goal,
+                         float* f, float* g, void* stream);
+int se3mpc_cost_grad_f64(const se3mpc_params* p, int B, int ld, const double* X, const double* goal,
+                         double* f, double* g, void* stream);
+
+/* Equality residuals of the translational dynamics, replaces _dynamics_constraints
+ * (planner.py:426-462).  R: [6N][ld], row order as the reference: P0-p0 (3), V0-v0 (3), then
+ * per k = 0..N-2 the position residual (3) and the velocity residual (3). */
+int se3mpc_dynamics_residual_f32(const se3mpc_params* p, int B, int ld, const float* X, const float* p0,
+                                 const float* v0, float* R, void* stream);
+int se3mpc_dynamics_residual_f64(const se3mpc_params* p, int B, int ld, const double* X, const double* p0,
+                                 const double* v0, double* R, void* stream);
+
+/* Sphere-obstacle inequality residuals, replaces _obstacle_constraints (planner.py:499-514).
+ * spheres: device [K][4] = (cx, cy, cz, radius), 0 <= K <= SE3MPC_MAX_SPHERES, staged in LDS.
+ * C: [N*K][ld] (row k*K + j) or NULL; cmin: [B] = min over (k,j) or NULL;
+ * viol: [B] = sum over (k,j) of max(0, -c) or NULL (the in-kernel reduced forms). */
+int se3mpc_obstacle_residual_f32(const se3mpc_params* p, int B, int ld, const float* X, const float* spheres,
+                                 int K, float* C, float* cmin, float* viol, void* stream);
+int se3mpc_obstacle_residual_f64(const se3mpc_params* p, int B, int ld, const double* X, const double* spheres,
+                                 int K, double* C, double* cmin, double* viol, void* stream);
+
+/* Replaces _physical_constraints (planner.py:472-497).  C: [4N][ld]: N velocity rows,
+ * N acceleration rows, then per k (max_thrust^2 - |T|^2, |T|^2 - min_thrust^2). */
+int se3mpc_physical_constraints_f32(const se3mpc_params* p, int B, int ld, const float* X, float* C, void* stream);
+int se3mpc_physical_constraints_f64(const se3mpc_params* p, int B, int ld, const double* X, double* C, void* stream);
+
+/* Replaces _extract_solution_from_result + _compute_attitudes_and_rates (planner.py:582-654).
+ * T: [3N][ld] (the T block of X).  acc, att, rates: [3N][ld]; thrust: [N][ld]; any may be NULL. */
+int se3mpc_extract_f32(const se3mpc_params* p, int B, int ld, const float* T, float* acc, float* att,
+                       float* rates, float* thrust, void* stream);
+int se3mpc_extract_f64(const se3mpc_params* p, int B, int ld, const double* T, double* acc, double* att,
+                       double* rates, double* thrust, void* stream);
+
+/* Shooting form (the build's canonical "rollout"): forward rollout of the
+ * recurrence that planner.py:449-460 writes as residuals, the objective of planner.py:516-550
+ * on the rolled-out states, and its exact gradient wrt the thrust sequence by the reverse
+ * sweep.  cost: [B]; gradT: [3N][ld] or NULL; P, V: [3N][ld] or both NULL (rolled-out states).
+ * key: NULL, or a device word the kernel folds the batch argmin into (fused form of
+ * se3mpc_argmin_*: *key = min(*key, orderable(cost[b]) << 32 | (index_base + b)), one 64-bit
+ * atomic per wavefront); the CALLER presets *key to UINT64_MAX (memset 0xFF). */
+int se3mpc_rollout_cost_grad_f32(const se3mpc_params* p, int B, int ld, const float* p0, const float* v0,
+                                 const float* goal, const float* T, float* cost, float* gradT, float* P,
+                                 float* V, uint64_t* key, uint32_t index_base, void* stream);
+int se3mpc_rollout_cost_grad_f64(const se3mpc_params* p, int B, int ld, const double* p0, const double* v0,
+                                 const double* goal, const double* T, double* cost, double* gradT, double* P,
+                                 double* V, uint64_t* key, uint32_t index_base, void* stream);
+
+/* Tuning knob for measurements: which implementation of the rollout the entry point above
+ * launches.  0 = auto (default), 1 = exact-N register arrays (N in {6,20,30,50}; falls back to
+ * 2 otherwise), 2 = per-step state tiles staged in LDS, 3 = register-light reversible sweep.
+ * All three compute the same quantities. */
+int se3mpc_set_rollout_variant(int variant);
+
+/* Replaces is_plan_valid (planner.py:717-737): valid[b] = 1 iff all positions finite,
+ * z >= 0.1 and |v| <= 20.  P, V: [3N][ld] (V may be NULL). */
+int se3mpc_is_plan_valid_f32(const se3mpc_params* p, int B, int ld, const float* P, const float* V,
+                             int32_t* valid, void* stream);
+int se3mpc_is_plan_valid_f64(const se3mpc_params* p, int B, int ld, const double* P, const double* V,
+                             int32_t* valid, void* stream);
+
+/* Batch argmin: *key = min over b of (orderable(cost[b]) << 32 | (index_base + b)); the packed
+ * 64-bit key is what the multi-GPU path all-reduces with MIN.
+ * The function resets *key itself (stream-ordered).  Decode with se3mpc_key_*. */
+int se3mpc_argmin_f32(int B, const float* cost, uint32_t index_base, uint64_t* key, void* stream);
+int se3mpc_argmin_f64(int B, const double* cost, uint32_t index_base, uint64_t* key, void* stream);
+uint32_t se3mpc_key_index(uint64_t key);
+float se3mpc_key_cost(uint64_t key);   /* f64 costs are ordered through their float rounding */
+
+/* [rows][ld_in] <-> [cols][ld_out] tiled transpose through LDS (layout conversion). */
+int se3mpc_transpose_f32(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, void* stream);
+int se3mpc_transpose_f64(int rows, int cols, const double* in, int ld_in, double* out, int ld_out, void* stream);
+
+/* ------------------------------------------------------------------ problem layout: [b][row]
+ * The batched solve: replaces _solve_se3_mpc (planner.py:230-280) = cold start (or a caller
+ * x0), box, scipy.optimize.minimize(method="L-BFGS-B", jac=..., bounds=..., maxiter, gtol,
+ * ftol) and _extract_solution_from_result, for B independent problems, one wavefront each.
+ *   p0, v0, goal : [B][3]
+ *   x0           : [B][9N] warm start, or NULL for the reference cold start
+ *   X            : [B][9N] solution (result.x)
+ *   info         : [B] se3mpc_solve_info
+ *   acc, att, rates : [B][N][3], thrust : [B][N]   (any may be NULL)
+ * All accumulations that feed a branch of L-BFGS-B run in double; `_f32` keeps the vectors in
+ * float. */
+int se3mpc_solve_f32(const se3mpc_params* p, int B, const float* p0, const float* v0, const float* goal,
+                     const float* x0, float* X, se3mpc_solve_info* info, float* acc, float* att,
+                     float* rates, float* thrust, void* stream);
+int se3mpc_solve_f64(const se3mpc_params* p, int B, const double* p0, const double* v0, const double* goal,
+                     const double* x0, double* X, se3mpc_solve_info* info, double* acc, double* att,
+                     double* rates, double* thrust, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SE3MPC_H */

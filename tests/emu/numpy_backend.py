@@ -1,0 +1,33 @@
+"""Host-buffer array backend for dart_planner_amd.ops.Ops -- TEST INFRASTRUCTURE.
+Pairs with tests/emu/libse3mpc_emu.so (the product kernels compiled for the host)."""
+import numpy as np
+
+
+class NumpyBackend:
+    _dt = {"f32": np.float32, "f64": np.float64, "i32": np.int32, "i64": np.int64, "u8": np.uint8}
+
+    def empty(self, shape, kind):
+        return np.full(shape, 0x7B, dtype=np.uint8).view(np.uint8)[:0].copy() if False else \
+            np.frombuffer(bytearray(b"\x7b" * (int(np.prod(shape)) * np.dtype(self._dt[kind]).itemsize)),
+                          dtype=self._dt[kind]).reshape(shape)
+
+    def suffix(self, a):
+        if a.dtype == np.float32:
+            return "f32"
+        if a.dtype == np.float64:
+            return "f64"
+        raise TypeError(a.dtype)
+
+    def check(self, a, name):
+        if not isinstance(a, np.ndarray) or not a.flags["C_CONTIGUOUS"]:
+            raise ValueError(f"{name}: need a C-contiguous ndarray")
+        return a
+
+    def ptr(self, a):
+        return 0 if a is None else a.ctypes.data
+
+    def stream(self):
+        return 0
+
+    def to_host(self, a):
+        return a

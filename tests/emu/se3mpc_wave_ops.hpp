@@ -1,0 +1,38 @@
+// TEST-ONLY host stand-in for dart_planner_amd/csrc/se3mpc_wave_ops.hpp (same API, lanes are
+// std::threads that rendezvous in emu::exchange).  The DPP code itself is validated on the GPU by
+// se3mpc_selftest (tests/test_gpu_parity.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace se3mpc {
+
+template <typename T, typename OP>
+inline T emu_wave_reduce(T v, OP op) {
+  // gather all 64 lanes in lane order so the summation order is deterministic
+  T acc{};
+  const int base = (int)threadIdx.x - (int)(threadIdx.x % 64);
+  for (int l = 0; l < 64; ++l) {
+    T x = ::emu::exchange(v, base + l);
+    acc = (l == 0) ? x : op(acc, x);
+  }
+  return acc;
+}
+inline double wave_sum(double v) { return emu_wave_reduce(v, [](double a, double b) { return a + b; }); }
+inline double wave_max(double v) { return emu_wave_reduce(v, [](double a, double b) { return a > b ? a : b; }); }
+inline double wave_min(double v) { return emu_wave_reduce(v, [](double a, double b) { return a < b ? a : b; }); }
+inline uint32_t wave_min_u32(uint32_t v) { return emu_wave_reduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+inline int wave_sum_i32(int v) { return emu_wave_reduce(v, [](int a, int b) { return a + b; }); }
+inline uint64_t wave_ballot(bool pred) {
+  uint64_t m = 0;
+  const int base = (int)threadIdx.x - (int)(threadIdx.x % 64);
+  for (int l = 0; l < 64; ++l) m |= (uint64_t)(::emu::exchange<int>(pred ? 1 : 0, base + l) & 1) << l;
+  return m;
+}
+inline int first_lane(uint64_t mask) { return mask ? __builtin_ctzll(mask) : -1; }
+inline double wave_bcast(double v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
+inline float wave_bcast(float v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
+inline int wave_bcast(int v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
+inline int lane_id() { return (int)(threadIdx.x & 63u); }
+
+}  // namespace se3mpc
