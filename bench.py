@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- SE(3) rollouts/s (horizon 30, batch 8192 per GPU) on N MI355X + roofline + CPU baseline.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 it is launched by
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (one rank per GPU,
+RCCL).  Rank 0 prints ONE JSON line.
+
+A *step* is one pass of the hot path over one batch: the shooting-form rollout + running/terminal
+cost + exact thrust gradient (SURVEY.md section 8d "canonical rollout", 4*(6N+10) B per rollout) of
+``batch`` synthetic trajectories resident in HBM, with the batch argmin folded into the same
+kernel.  The batch is fixed per GPU (weak scaling); the only cross-GPU exchange is ONE bucketed
+RCCL all-reduce(MIN) of the K packed (cost, index) keys at the end of the timed region
+(SURVEY.md section 8e).  Steps cycle through a ring of distinct input/output batches larger than the
+256 MiB Infinity Cache, so every step streams its operands from HBM; the K launches are
+captured once into a hipGraph (launch-bound inner loop) and replayed inside the timed region.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=8192, help="rollouts per GPU per step (BASELINE.json metric: 8192)")
+    ap.add_argument("--horizon", type=int, default=30)
+    ap.add_argument("--ring", type=int, default=0, help="distinct batches cycled through (0 = enough to exceed 512 MiB)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--variant", type=int, default=0, help="se3mpc_set_rollout_variant (0 = auto)")
+    ap.add_argument("--sweep", action="store_true", help="also time saturating batch sizes (extra keys)")
+    return ap.parse_args()
+
+
+def make_ring(torch, dev, B, N, ring, seed):
+    """cfg-2 distribution of SURVEY.md section 8d: p0 ~ U(-20,20)^3, v0 ~ U(-5,5)^3, goal ~ U(-20,20)^3,
+    T = (0,0,14.715) + N(0, 2^2) clipped to the thrust box (planner.py:390-400)."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    p0 = torch.rand(ring, 3, B, device=dev, generator=g) * 40 - 20
+    v0 = torch.rand(ring, 3, B, device=dev, generator=g) * 10 - 5
+    goal = torch.rand(ring, 3, B, device=dev, generator=g) * 40 - 20
+    T = torch.randn(ring, 3 * N, B, device=dev, generator=g) * 2
+    T[:, 2::3] += 14.715
+    txy = 25.0 * math.sin(math.pi / 4)
+    T[:, 0::3].clamp_(-txy, txy); T[:, 1::3].clamp_(-txy, txy); T[:, 2::3].clamp_(2.0, 25.0)
+    cost = torch.empty(ring, B, device=dev)
+    grad = torch.empty(ring, 3 * N, B, device=dev)
+    return p0, v0, goal, T, cost, grad
+
+
+def cpu_baseline(B, N, seconds):
+    """The oracle's batched NumPy restatement of the same rollout+cost+gradient, float64, on the
+    host cores of this box (NumPy elementwise kernels are single-threaded: cores = 1)."""
+    from oracle import se3mpc_oracle as orc
+    cfg = orc.OracleConfig(prediction_horizon=N)
+    rng = np.random.default_rng(1)
+    Bs = min(B, 8192)
+    p0, v0, goal = rng.uniform(-20, 20, (Bs, 3)), rng.uniform(-5, 5, (Bs, 3)), rng.uniform(-20, 20, (Bs, 3))
+    T = rng.normal(0, 2, (Bs, N, 3)) + [0, 0, cfg.hover_thrust]
+    orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+        n += 1
+    el = time.perf_counter() - t0
+    # reference-shaped leg: one problem per call, Python loops as in planner.py:516-580
+    x = orc.straight_line_init(p0[0], v0[0], goal[0], cfg)
+    m, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < min(3.0, seconds / 3):
+        orc.objective_loops(x, goal[0], cfg); orc.gradient_loops(x, goal[0], cfg)
+        m += 1
+    el1 = time.perf_counter() - t1
+    return dict(value=n * Bs / el, unit="rollouts/s", cores=1, kind="port",
+                sample=f"{n} passes of the oracle's batched NumPy rollout+cost+grad (float64) over {Bs} trajectories, horizon {N}, {el:.1f} s",
+                reference_shaped_evals_per_s=m / el1, host_cpus=os.cpu_count())
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if a.gpus != world and rank == 0:
+        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1", file=sys.stderr)
+
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd.ops import Ops, TorchBackend
+    ops = Ops(TorchBackend(dev))
+    ops.lib.set_rollout_variant(a.variant)
+    B, N, K, W = a.batch, a.horizon, a.steps, a.warmup
+    prm = Params.reference_defaults(horizon=N)
+    bytes_per_rollout = 4 * (6 * N + 10)
+    slot_bytes = 4 * B * ((9 + 3 * N) + (1 + 3 * N))
+    ring = a.ring if a.ring > 0 else max(2, math.ceil(512 * 2 ** 20 / slot_bytes))
+    p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=3 + rank)
+    keys = torch.full((max(K, W, 1),), -1, dtype=torch.int64, device=dev)     # UINT64_MAX
+    base = rank * B
+
+    def step(i):
+        s = i % ring
+        ops.rollout_cost_grad(prm, p0[s], v0[s], goal[s], T[s], out=(cost[s], grad[s]), key=keys[i:i + 1], index_base=base)
+
+    for i in range(W):                                          # untimed warm-up (eager)
+        step(i)
+    torch.cuda.synchronize()
+    keys.fill_(-1)
+
+    graph = None
+    if not a.no_graph:
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for i in range(K):
+                    step(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph.replay()                                          # one untimed replay (uploads the graph)
+        torch.cuda.synchronize()
+        keys.fill_(-1)
+        torch.cuda.synchronize()
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        for i in range(K):
+            step(i)
+    e1.record()
+    if world > 1:
+        # the single exchange: bucketed all-reduce(MIN) of the K packed keys (sign bit flipped so the
+        # signed int64 order RCCL reduces in equals the unsigned key order)
+        skeys = keys[:K] ^ torch.iinfo(torch.int64).min
+        dist.all_reduce(skeys, op=dist.ReduceOp.MIN)
+        keys[:K] = skeys ^ torch.iinfo(torch.int64).min
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    kernel_ms = e0.elapsed_time(e1) / K                        # launch-to-launch time of the dominant kernel
+    # sanity: every step produced a key that indexes into the global batch
+    kh = keys[:K].cpu().numpy().astype(np.uint64)
+    idx_ok = bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B)))
+
+    if rank == 0:
+        achieved = bytes_per_rollout * B / (kernel_ms * 1e-3) / 1e9
+        res = {
+            "metric": "SE(3) rollouts/sec (N=30, batch=8192) + p95 solve ms, at 1/2/4/8 MI355X",
+            "value": world * B * K / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"horizon={N} SE(3) rollout + cost + thrust-gradient (+ fused batch argmin), "
+                                   f"batch={B} per GPU per step, ring of {ring} distinct batches in HBM "
+                                   f"({ring * slot_bytes / 2 ** 20:.0f} MiB), "
+                                   f"{'hipGraph replay of K launches' if graph is not None else 'eager launches'}",
+                       "horizon": N, "batch_per_gpu": B, "global_batch": world * B, "ring": ring,
+                       "parallelism": f"batch-sharded x{world}, one bucketed all-reduce(MIN) of {K} keys"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "rollout_reg_kernel<float,30,grad>", "kernel_us": kernel_ms * 1e3,
+                         "bytes_per_launch": bytes_per_rollout * B,
+                         "note": "achieved = algorithmic bytes (4*(6N+10) B/rollout x batch) / average launch-to-launch "
+                                 "time over the timed region (HIP events around the K launches on the launch stream)"},
+            "keys_valid": idx_ok,
+        }
+        if a.sweep:
+            res["sweep"] = sweep(torch, ops, prm, dev, N)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(B, N, a.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def sweep(torch, ops, prm, dev, N):
+    """Saturating batches (one launch each, eager): where the HBM roofline is actually reachable."""
+    out = []
+    for B in (65536, 1 << 20, 1 << 22):
+        p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, 2, seed=11)
+        for _ in range(3):
+            ops.rollout_cost_grad(prm, p0[0], v0[0], goal[0], T[0], out=(cost[0], grad[0]))
+        torch.cuda.synchronize()
+        reps = 40
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(reps):
+            ops.rollout_cost_grad(prm, p0[i & 1], v0[i & 1], goal[i & 1], T[i & 1], out=(cost[i & 1], grad[i & 1]))
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        gbps = 4 * (6 * N + 10) * B / (ms * 1e-3) / 1e9
+        out.append({"batch": B, "kernel_us": ms * 1e3, "rollouts_per_s": B / (ms * 1e-3), "GB_per_s": gbps,
+                    "frac_of_peak": gbps / HBM_PEAK_GBPS})
+        del p0, v0, goal, T, cost, grad
+    return out
+
+
+if __name__ == "__main__":
+    main()

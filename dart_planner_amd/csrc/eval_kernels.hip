@@ -275,13 +275,11 @@ template <typename R>
 __device__ __forceinline__ void rollout_epilogue(bool live, int b, R c, R* __restrict__ cost,
                                                  unsigned long long* __restrict__ key, uint32_t index_base) {
   if (live) cost[b] = c;
-  if (key != nullptr) {
-    const uint32_t bits = live ? orderable_bits((float)c) : 0xFFFFFFFFu;
-    const uint32_t m = wave_min_u32(bits);
-    const int src = first_lane(wave_ballot(live && bits == m));
-    if (src >= 0 && lane_id() == src)
-      atomicMin(key, ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b));
-  }
+  const uint32_t bits = live ? orderable_bits((float)c) : 0xFFFFFFFFu;
+  const uint32_t m = wave_min_u32(bits);
+  const int src = first_lane(wave_ballot(live && bits == m));
+  if (key != nullptr && src >= 0 && lane_id() == src)
+    atomicMin(key, ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b));
 }
 
 template <typename R>
@@ -296,62 +294,168 @@ __device__ __forceinline__ R rollout_total(const DevParams<R>& q, const RolloutS
   return c;
 }
 
+// Per-axis constants of the sweeps, hoisted out of the k loops.
+template <typename R>
+struct AxisConsts {
+  R gl, grav, hov, two_wp, two_wv, c_aa, c_tt, c_lp, c_lv;
+};
+
+template <typename R>
+__device__ __forceinline__ AxisConsts<R> axis_consts(const DevParams<R>& q, int a, R gl) {
+  AxisConsts<R> c;
+  c.gl = gl;
+  c.grav = (a == 2) ? q.grav : (R)0;
+  c.hov = (a == 2) ? q.hover : (R)0;
+  c.two_wp = q.has_goal ? (R)2 * q.wp : (R)0;
+  c.two_wv = (R)2 * q.wv;
+  c.c_aa = (R)2 * q.wa * q.inv_mass;        // d(wa*acc^2)/dT
+  c.c_tt = (R)2 * q.wT;                     // d(wT*(T-hover)^2)/dT
+  c.c_lp = q.half_dt2 * q.inv_mass;         // dP_{k+1}/dT_k
+  c.c_lv = q.dt * q.inv_mass;               // dV_{k+1}/dT_k
+  return c;
+}
+
+// Weighted cost of ONE axis from its five sums of squares.
+template <typename R>
+__device__ __forceinline__ R axis_cost(const DevParams<R>& q, const RolloutSums<R>& s) {
+  R c = q.wv * s.sv + q.wa * s.sa + q.wT * s.st;
+  if (q.has_goal) c += q.wp * (s.sp + q.term * s.sterm);
+  return c;
+}
+
+// One axis of one trajectory with exact-N register arrays.  Loads of all N thrust rows are issued
+// back to back (N independent HBM requests in flight per lane) before the first use.
 template <typename R, int N, bool GRAD, bool STATES>
-__global__ void __launch_bounds__(64)
-rollout_reg_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
-                   const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
-                   R* __restrict__ gradT, R* __restrict__ Pout, R* __restrict__ Vout,
-                   unsigned long long* __restrict__ key, uint32_t index_base) {
-  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = b0 < B;
-  const int b = live ? b0 : B - 1;                         // tail lanes shadow the last trajectory (loads only)
+__device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
+                                              const R* __restrict__ v0, const R* __restrict__ goal,
+                                              const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
+                                              R* __restrict__ Vout) {
+  R t[N], es[N], vs[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    t[k] = lane_ld(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
+  }
+  const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
+  R p = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
+  R v = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
   RolloutSums<R> s = {0, 0, 0, 0, 0};
-  const R two_wp = q.has_goal ? (R)2 * q.wp : (R)0;
-  const size_t stride = (size_t)3 * ld;
-#pragma unroll 1
-  for (int a = 0; a < 3; ++a) {
-    R t[N], ps[N], vs[N];
-    const R* tp = T + (size_t)a * ld + b;
 #pragma unroll
-    for (int k = 0; k < N; ++k) { t[k] = *tp; tp += stride; }
-    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
-    const R grav = (a == 2) ? q.grav : (R)0;
-    const R hov = (a == 2) ? q.hover : (R)0;
-    R p = p0[(size_t)a * ld + b];
-    R v = v0[(size_t)a * ld + b];
-#pragma unroll
-    for (int k = 0; k < N; ++k) {
-      ps[k] = p; vs[k] = v;
-      const R acc = t[k] * q.inv_mass - grav;
-      const R e = p - gl;
-      const R dev = t[k] - hov;
-      s.sp += e * e; s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
-      if (k == N - 1) s.sterm += e * e;
-      p = p + v * q.dt + q.half_dt2 * acc;                 // planner.py:450-455 solved for P_{k+1}
-      v = v + acc * q.dt;                                  // planner.py:459 solved for V_{k+1}
-    }
+  for (int k = 0; k < N; ++k) {
+    const R acc = t[k] * q.inv_mass - c.grav;
+    const R dev = t[k] - c.hov;
+    const R e = p - c.gl;
+    es[k] = e; vs[k] = v;
+    if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
+    s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
     if (STATES) {
-      R* pp = Pout + (size_t)a * ld + b;
-      R* vp = Vout + (size_t)a * ld + b;
-#pragma unroll
-      for (int k = 0; k < N; ++k) { if (live) { *pp = ps[k]; *vp = vs[k]; } pp += stride; vp += stride; }
+      lane_st(lane_buf(Pout), voff, (unsigned)(3 * k + a) * rowb, p);
+      lane_st(lane_buf(Vout), voff, (unsigned)(3 * k + a) * rowb, v);
     }
-    if (GRAD) {
-      R lamP = two_wp * ((R)1 + q.term) * (ps[N - 1] - gl);
-      R lamV = (R)2 * q.wv * vs[N - 1];
-      R* gp = gradT + (size_t)a * ld + b + (size_t)(N - 1) * stride;
-      if (live) *gp = (R)2 * q.wa * (t[N - 1] * q.inv_mass - grav) * q.inv_mass + (R)2 * q.wT * (t[N - 1] - hov);
+    p = p + v * q.dt + q.half_dt2 * acc;                   // planner.py:450-455 solved for P_{k+1}
+    v = v + acc * q.dt;                                    // planner.py:459 solved for V_{k+1}
+  }
+  s.sp += s.sterm;
+  if (GRAD) {
+    R lamP = c.two_wp * ((R)1 + q.term) * es[N - 1];
+    R lamV = c.two_wv * vs[N - 1];
+    lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (t[N - 1] * q.inv_mass - c.grav) + c.c_tt * (t[N - 1] - c.hov));
 #pragma unroll
-      for (int k = N - 2; k >= 0; --k) {
-        gp -= stride;
-        const R acc = t[k] * q.inv_mass - grav;
-        if (live) *gp = (R)2 * q.wa * acc * q.inv_mass + (R)2 * q.wT * (t[k] - hov) + (q.half_dt2 * lamP + q.dt * lamV) * q.inv_mass;
-        lamV = (R)2 * q.wv * vs[k] + q.dt * lamP + lamV;
-        lamP = two_wp * (ps[k] - gl) + lamP;
-      }
+    for (int k = N - 2; k >= 0; --k) {
+      const R acc = t[k] * q.inv_mass - c.grav;
+      const R dev = t[k] - c.hov;
+      lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
+      lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
+      lamP = c.two_wp * es[k] + lamP;
     }
   }
-  rollout_epilogue<R>(live, b, rollout_total(q, s), cost, key, index_base);
+  return axis_cost(q, s);
+}
+
+// Any N, O(1) registers: the reverse sweep re-reads T_k (L2) and walks the states backwards
+// through the inverted recurrence instead of storing them.
+template <typename R, bool GRAD, bool STATES>
+__device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
+                                              const R* __restrict__ v0, const R* __restrict__ goal,
+                                              const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
+                                              R* __restrict__ Vout) {
+  const int N = q.N;
+  const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
+  R p = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
+  R v = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
+  RolloutSums<R> s = {0, 0, 0, 0, 0};
+  R tk = (R)0, pl = p, vl = v;
+#pragma unroll 6
+  for (int k = 0; k < N; ++k) {
+    tk = lane_ld(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
+    const R acc = tk * q.inv_mass - c.grav;
+    const R dev = tk - c.hov;
+    const R e = p - c.gl;
+    if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
+    s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+    if (STATES) {
+      lane_st(lane_buf(Pout), voff, (unsigned)(3 * k + a) * rowb, p);
+      lane_st(lane_buf(Vout), voff, (unsigned)(3 * k + a) * rowb, v);
+    }
+    pl = p; vl = v;                                         // state at step k (P_{N-1}, V_{N-1} after the loop)
+    p = p + v * q.dt + q.half_dt2 * acc;
+    v = v + acc * q.dt;
+  }
+  s.sp += s.sterm;
+  if (GRAD) {
+    R lamP = c.two_wp * ((R)1 + q.term) * (pl - c.gl);
+    R lamV = c.two_wv * vl;
+    lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (tk * q.inv_mass - c.grav) + c.c_tt * (tk - c.hov));
+    R pk = pl, vk = vl;
+#pragma unroll 6
+    for (int k = N - 2; k >= 0; --k) {
+      const R t = lane_ld(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
+      const R acc = t * q.inv_mass - c.grav;
+      const R dev = t - c.hov;
+      vk = vk - acc * q.dt;                                 // V_k from V_{k+1}
+      pk = pk - vk * q.dt - q.half_dt2 * acc;               // P_k from P_{k+1}
+      lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
+      lamV = c.two_wv * vk + q.dt * lamP + lamV;
+      lamP = c.two_wp * (pk - c.gl) + lamP;
+    }
+  }
+  return axis_cost(q, s);
+}
+
+// Kernel shells.  SPLIT: a 192-thread workgroup owns 64 trajectories, wavefront w = axis w; the
+// three partial costs meet in LDS ([3][64] values), then every wavefront runs the (uniform)
+// epilogue and wavefront 0 commits it.  !SPLIT: one wavefront per 64 trajectories loops the axes.
+template <typename R, int N, bool REG, bool SPLIT, bool GRAD, bool STATES>
+__global__ void __launch_bounds__(SPLIT ? 192 : 64)
+rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+               const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost, R* __restrict__ gradT,
+               R* __restrict__ Pout, R* __restrict__ Vout, unsigned long long* __restrict__ key, uint32_t index_base) {
+  const int lane = threadIdx.x & (kWave - 1);
+  const int b0 = blockIdx.x * kWave + lane;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;          // tail lanes shadow the last trajectory: identical loads, identical
+                                            // (benign duplicate) stores, no contribution to cost/key
+  const unsigned voff = (unsigned)b * (unsigned)sizeof(R);    // the lane's byte offset inside a row
+  const unsigned rowb = (unsigned)ld * (unsigned)sizeof(R);   // bytes per row (wave-uniform)
+  R total;
+  if constexpr (SPLIT) {
+    __shared__ R part[3][kWave];
+    const int a = wave_uniform((int)(threadIdx.x / kWave));   // wave index -> SGPR, so row bases stay scalar
+    R c;
+    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+    else c = rollout_axis_rev<R, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+    part[a][lane] = c;
+    __syncthreads();
+    total = part[0][lane] + part[1][lane] + part[2][lane];
+    rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0) ? key : nullptr, index_base);
+  } else {
+    total = (R)0;
+#pragma unroll 1
+    for (int a = 0; a < 3; ++a) {
+      if constexpr (REG) total += rollout_axis_reg<R, N, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+      else total += rollout_axis_rev<R, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+    }
+    rollout_epilogue<R>(live, b, total, cost, key, index_base);
+  }
 }
 
 template <typename R, bool GRAD, bool STATES>
@@ -408,66 +512,6 @@ rollout_lds_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, cons
         const R t = *tp;
         const R pk = tile[(2 * k) * kWave + lane], vk = tile[(2 * k + 1) * kWave + lane];
         const R acc = t * q.inv_mass - grav;
-        if (live) *gp = (R)2 * q.wa * acc * q.inv_mass + (R)2 * q.wT * (t - hov) + (q.half_dt2 * lamP + q.dt * lamV) * q.inv_mass;
-        lamV = (R)2 * q.wv * vk + q.dt * lamP + lamV;
-        lamP = two_wp * (pk - gl) + lamP;
-      }
-    }
-  }
-  rollout_epilogue<R>(live, b, rollout_total(q, s), cost, key, index_base);
-}
-
-template <typename R, bool GRAD, bool STATES>
-__global__ void __launch_bounds__(64)
-rollout_rev_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
-                   const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
-                   R* __restrict__ gradT, R* __restrict__ Pout, R* __restrict__ Vout,
-                   unsigned long long* __restrict__ key, uint32_t index_base) {
-  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = b0 < B;
-  const int b = live ? b0 : B - 1;
-  const int N = q.N;
-  RolloutSums<R> s = {0, 0, 0, 0, 0};
-  const R two_wp = q.has_goal ? (R)2 * q.wp : (R)0;
-  const size_t stride = (size_t)3 * ld;
-#pragma unroll 1
-  for (int a = 0; a < 3; ++a) {
-    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
-    const R grav = (a == 2) ? q.grav : (R)0;
-    const R hov = (a == 2) ? q.hover : (R)0;
-    R p = p0[(size_t)a * ld + b];
-    R v = v0[(size_t)a * ld + b];
-    const R* tp = T + (size_t)a * ld + b;
-    R* pp = STATES ? Pout + (size_t)a * ld + b : nullptr;
-    R* vp = STATES ? Vout + (size_t)a * ld + b : nullptr;
-    R tk = (R)0, pl = p, vl = v;
-#pragma unroll 4
-    for (int k = 0; k < N; ++k) {
-      tk = *tp; tp += stride;
-      if (STATES) { if (live) { *pp = p; *vp = v; } pp += stride; vp += stride; }
-      const R acc = tk * q.inv_mass - grav;
-      const R e = p - gl;
-      const R dev = tk - hov;
-      s.sp += e * e; s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
-      if (k == N - 1) s.sterm += e * e;
-      pl = p; vl = v;                                       // state at step k (P_{N-1}, V_{N-1} after the loop)
-      p = p + v * q.dt + q.half_dt2 * acc;
-      v = v + acc * q.dt;
-    }
-    if (GRAD) {
-      R lamP = two_wp * ((R)1 + q.term) * (pl - gl);
-      R lamV = (R)2 * q.wv * vl;
-      R* gp = gradT + (size_t)a * ld + b + (size_t)(N - 1) * stride;
-      if (live) *gp = (R)2 * q.wa * (tk * q.inv_mass - grav) * q.inv_mass + (R)2 * q.wT * (tk - hov);
-      tp -= stride;
-      R pk = pl, vk = vl;                                   // walk the states backwards
-#pragma unroll 4
-      for (int k = N - 2; k >= 0; --k) {
-        gp -= stride; tp -= stride;
-        const R t = *tp;
-        const R acc = t * q.inv_mass - grav;
-        vk = vk - acc * q.dt;                               // V_k from V_{k+1}
-        pk = pk - vk * q.dt - q.half_dt2 * acc;             // P_k from P_{k+1}
         if (live) *gp = (R)2 * q.wa * acc * q.inv_mass + (R)2 * q.wT * (t - hov) + (q.half_dt2 * lamP + q.dt * lamV) * q.inv_mass;
         lamV = (R)2 * q.wv * vk + q.dt * lamP + lamV;
         lamP = two_wp * (pk - gl) + lamP;
@@ -556,7 +600,7 @@ static inline int check_lane_args(const se3mpc_params* p, int B, int ld) {
   if (p == nullptr) return SE3MPC_ERR_NULL;
   const int rc = check_params_impl(p);
   if (rc != SE3MPC_OK) return rc;
-  if (B < 0 || ld < B) return SE3MPC_ERR_SHAPE;
+  if (B < 0 || ld < B || ld > (1 << 28)) return SE3MPC_ERR_SHAPE;   // lane byte offsets stay 32-bit
   return SE3MPC_OK;
 }
 
@@ -632,45 +676,43 @@ int extract_impl(const se3mpc_params* p, int B, int ld, const R* T, R* acc, R* a
   return launch_status("se3mpc_extract");
 }
 
-static int g_rollout_variant = 0;   // 0 auto, 1 REG, 2 LDS, 3 REV
+static int g_rollout_variant = 0;   // 0 auto, 1 REG split, 2 LDS, 3 REV split, 4 REG mono, 5 REV mono
 
 template <typename R, bool GRAD, bool STATES>
 int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* p0, const R* v0, const R* goal,
                    const R* T, R* cost, R* gradT, R* P, R* V, unsigned long long* key, uint32_t index_base,
                    hipStream_t s) {
   const DevParams<R> q = make_dev_params<R>(*p);
-  const dim3 grid(grid_for(B, kLaneBlock)), block(kLaneBlock);
+  const int nblk = grid_for(B, kWave);
   const int N = p->horizon;
-  // f64 register arrays spill beyond N = 20 (2 VGPRs per value)
+  // exact-N register kernels exist for the BASELINE horizons; f64 arrays spill beyond N = 20
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
   if (variant == 0) variant = has_reg ? 1 : 3;
-  if (variant == 1 && !has_reg) variant = 3;
-  if (variant == 1) {
-#define SE3MPC_REG_CASE(NN)                                                                                         \
-  case NN:                                                                                                          \
-    hipLaunchKernelGGL((rollout_reg_kernel<R, NN, GRAD, STATES>), grid, block, 0, s, q, B, ld, p0, v0, goal, T, cost, \
-                       gradT, P, V, key, index_base);                                                               \
-    break;
-    switch (N) {
-      SE3MPC_REG_CASE(6)
-      SE3MPC_REG_CASE(20)
-      default:
-        if constexpr (sizeof(R) == 4) {
-          switch (N) {
-            SE3MPC_REG_CASE(30)
-            SE3MPC_REG_CASE(50)
-          }
-        }
-    }
-#undef SE3MPC_REG_CASE
-  } else if (variant == 2) {
-    const size_t lds = (size_t)2 * N * kWave * sizeof(R);
-    hipLaunchKernelGGL((rollout_lds_kernel<R, GRAD, STATES>), grid, block, lds, s, q, B, ld, p0, v0, goal, T, cost,
-                       gradT, P, V, key, index_base);
-  } else {
-    hipLaunchKernelGGL((rollout_rev_kernel<R, GRAD, STATES>), grid, block, 0, s, q, B, ld, p0, v0, goal, T, cost,
-                       gradT, P, V, key, index_base);
+  if ((variant == 1 || variant == 4) && !has_reg) variant = (variant == 1) ? 3 : 5;
+#define SE3MPC_LAUNCH(NN, REG, SPLIT)                                                                               \
+  hipLaunchKernelGGL((rollout_kernel<R, NN, REG, SPLIT, GRAD, STATES>), dim3(nblk), dim3(SPLIT ? 192 : 64), 0, s, q,  \
+                     B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base)
+#define SE3MPC_REG_SWITCH(SPLIT)                                                                                    \
+  switch (N) {                                                                                                      \
+    case 6: SE3MPC_LAUNCH(6, true, SPLIT); break;                                                                   \
+    case 20: SE3MPC_LAUNCH(20, true, SPLIT); break;                                                                 \
+    default:                                                                                                        \
+      if constexpr (sizeof(R) == 4) {                                                                               \
+        if (N == 30) SE3MPC_LAUNCH(30, true, SPLIT);                                                                \
+        else SE3MPC_LAUNCH(50, true, SPLIT);                                                                        \
+      }                                                                                                             \
   }
+  if (variant == 1) { SE3MPC_REG_SWITCH(true) }
+  else if (variant == 4) { SE3MPC_REG_SWITCH(false) }
+  else if (variant == 3) SE3MPC_LAUNCH(0, false, true);
+  else if (variant == 5) SE3MPC_LAUNCH(0, false, false);
+  else {
+    const size_t lds = (size_t)2 * N * kWave * sizeof(R);
+    hipLaunchKernelGGL((rollout_lds_kernel<R, GRAD, STATES>), dim3(nblk), dim3(kWave), lds, s, q, B, ld, p0, v0, goal,
+                       T, cost, gradT, P, V, key, index_base);
+  }
+#undef SE3MPC_REG_SWITCH
+#undef SE3MPC_LAUNCH
   return launch_status("se3mpc_rollout_cost_grad");
 }
 
@@ -683,6 +725,7 @@ int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !T || !cost || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
   if ((P == nullptr) != (V == nullptr)) return SE3MPC_ERR_NULL;   // states come as a pair
+  if ((uint64_t)3 * p->horizon * (uint64_t)ld * sizeof(R) >= (1ull << 32)) return SE3MPC_ERR_SHAPE;   // 32-bit buffer offsets
   hipStream_t s = (hipStream_t)stream;
   const int var = g_rollout_variant;
   const bool grad = gradT != nullptr, states = P != nullptr;
@@ -776,7 +819,7 @@ using namespace se3mpc;
   }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant > 3) return SE3MPC_ERR_SHAPE;
+  if (variant < 0 || variant > 5) return SE3MPC_ERR_SHAPE;
   se3mpc::g_rollout_variant = variant;
   return SE3MPC_OK;
 }

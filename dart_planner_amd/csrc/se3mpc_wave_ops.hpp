@@ -106,6 +106,39 @@ __device__ __forceinline__ float wave_bcast(float v, int src) {
 }
 __device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
+// ---- lane-layout memory access through a buffer resource (SRSRC) ---------------------------
+// address = base (descriptor, 4 SGPRs) + soff (SGPR: row * ld * sizeof(R), wave-uniform) + voff
+// (ONE VGPR: lane * sizeof(R)) -> `buffer_load_dword v, v_off, s[rsrc], s_row offen`.  No 64-bit
+// vector address arithmetic and no per-row address VGPRs, so all N row loads of a sweep can be
+// in flight at once.  Offsets are 32-bit: rows*ld*sizeof(R) < 4 GiB is checked on the host.
+template <typename R>
+struct LaneBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+};
+template <typename R>
+__device__ __forceinline__ LaneBuf<R> lane_buf(const R* base) {
+  LaneBuf<R> b;
+  // raw buffer (stride 0), num_records = max, DWORD3 = 0x00020000 (gfx9 family: 32-bit data format)
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<R*>(base), 0, 0xFFFFFFFF, 0x00020000);
+  return b;
+}
+__device__ __forceinline__ float lane_ld(const LaneBuf<float>& b, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rsrc, voff, soff, 0));
+}
+__device__ __forceinline__ double lane_ld(const LaneBuf<double>& b, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, voff, soff, 0));
+}
+__device__ __forceinline__ void lane_st(const LaneBuf<float>& b, unsigned voff, unsigned soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.rsrc, voff, soff, 0);
+}
+__device__ __forceinline__ void lane_st(const LaneBuf<double>& b, unsigned voff, unsigned soff, double v) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b.rsrc, voff, soff, 0);
+}
+
+// Tell the compiler a value is the same in every lane (moves it to an SGPR).
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
 
 }  // namespace se3mpc

@@ -33,6 +33,19 @@ inline int first_lane(uint64_t mask) { return mask ? __builtin_ctzll(mask) : -1;
 inline double wave_bcast(double v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
 inline float wave_bcast(float v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
 inline int wave_bcast(int v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
+template <typename R>
+struct LaneBuf { const char* base; };
+template <typename R>
+inline LaneBuf<R> lane_buf(const R* base) { return LaneBuf<R>{reinterpret_cast<const char*>(base)}; }
+template <typename R>
+inline R lane_ld(const LaneBuf<R>& b, unsigned voff, unsigned soff) {
+  return *reinterpret_cast<const R*>(b.base + (size_t)soff + voff);
+}
+template <typename R>
+inline void lane_st(const LaneBuf<R>& b, unsigned voff, unsigned soff, R v) {
+  *reinterpret_cast<R*>(const_cast<char*>(b.base) + (size_t)soff + voff) = v;
+}
+inline int wave_uniform(int v) { return v; }
 inline int lane_id() { return (int)(threadIdx.x & 63u); }
 
 }  // namespace se3mpc

@@ -29,7 +29,7 @@ for dt, tname in ((torch.float64, "f64"), (torch.float32, "f32")):
         p0, v0, goal = rng.uniform(-20, 20, (B, 3)), rng.uniform(-5, 5, (B, 3)), rng.uniform(-20, 20, (B, 3))
         T = rng.normal(0, 2, (B, N, 3)) + [0, 0, cfg.hover_thrust]
         c_ref, g_ref = orc.rollout_cost_grad(p0, v0, goal, T, cfg)
-        for var in (1, 2, 3):
+        for var in (1, 2, 3, 4, 5):
             lib.set_rollout_variant(var)
             cost, gT, P, V = ops.rollout_cost_grad(prm, lane(p0, B, dt), lane(v0, B, dt), lane(goal, B, dt), lane(T, B, dt), want_states=True)
             torch.cuda.synchronize()
@@ -61,7 +61,7 @@ for B in (8192, 65536, 1 << 20, 1 << 22):
     T = torch.randn(3 * N, B, device=dev, generator=g) * 2
     T[2::3] += 14.715
     cost = torch.empty(B, device=dev); gT = torch.empty(3 * N, B, device=dev)
-    for var in (1, 2, 3):
+    for var in (1, 3, 4, 5, 2):
         lib.set_rollout_variant(var)
         for _ in range(5):
             ops.rollout_cost_grad(prm, p0, v0, goal, T, out=(cost, gT))
