@@ -33,7 +33,13 @@ __global__ void init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__
       if (q.has_goal) {
         const R alpha = (R)i / denom;                       // planner.py:344
         pi = ((R)1 - alpha) * p + alpha * g;                // planner.py:345-347
-        vi = (i == 0) ? v : (pi - prev) / q.dt;             // planner.py:339, :350
+        if constexpr (sizeof(R) == 4) {
+          // float32: (P_i - P_{i-1})/dt loses ~|P| * 6e-8 / dt ~ 1e-3 m/s to cancellation; the
+          // algebraically identical (alpha_i - alpha_{i-1}) (goal - p0) / dt does not
+          vi = (i == 0) ? v : ((alpha - (R)(i - 1) / denom) * (g - p)) / q.dt;
+        } else {
+          vi = (i == 0) ? v : (pi - prev) / q.dt;           // planner.py:339, :350
+        }
       } else {
         pi = p;                                             // planner.py:356
         vi = (i == 0) ? v : (R)0;

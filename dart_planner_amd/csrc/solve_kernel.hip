@@ -1,0 +1,894 @@
+// solve_kernel.hip -- batched SE(3) MPC solve: one 64-lane wavefront per problem.
+//
+// Replaces SE3MPCPlanner._solve_se3_mpc (reference planner.py:230-280): cold start (:329-359),
+// box (:378-402), scipy.optimize.minimize(method="L-BFGS-B", jac=_objective_gradient, bounds,
+// maxiter, gtol, ftol) with the reference's objective/gradient pair (:516-580), and
+// _extract_solution_from_result (:582-654).  The L-BFGS-B is a from-scratch wavefront-parallel
+// implementation of the published algorithm (Byrd-Lu-Nocedal-Zhu 1995; Morales-Nocedal 2011;
+// More-Thuente line search), structured like oracle/lbfgsb_port.py which is pinned to SciPy.
+//
+// Mapping.  n = 9N <= 576 decision variables; lane L owns elements i = L + 64 j, j < J
+// (J = ceil(n/64) is a template parameter, so x, g, d, z, x_old, g_old live in registers).  Dot
+// products / norms / argmins are per-lane partials + a DPP wavefront reduction (no LDS).  The
+// L-BFGS pairs S, Y (m x n) live in LDS, each lane touching only its own elements (bank = lane:
+// conflict free).  The m x m / 2m x 2m middle matrices and their Cholesky / triangular solves
+// are "scalar sections": lane 0 runs them on LDS, the wavefront re-converges at a barrier and
+// reads the results as LDS broadcasts.  Every quantity that feeds a branch of the algorithm is
+// computed in double; the _f32 entry point only stores S, Y and the results in float.
+// No global memory is touched between reading (p0, v0, goal[, x0]) and writing the results.
+#include <hip/hip_runtime.h>
+
+#include "se3mpc_common.hpp"
+#include <se3mpc_wave_ops.hpp>
+
+namespace se3mpc {
+
+constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON (epsmch)
+constexpr double kBig = 1.0e10;
+constexpr double kInf = __builtin_huge_val();
+
+struct SolveDev {
+  int N, n, has_goal, m, maxiter, maxls, maxfun;
+  double dt, mass, grav, hover, wp, wv, wa, wT, term;
+  double pos_b, v_max, txy, tz_lo, tz_hi;
+  double pgtol, ftol;
+};
+
+static SolveDev make_solve_dev(const se3mpc_params& p) {
+  SolveDev d;
+  d.N = p.horizon; d.n = 9 * p.horizon; d.has_goal = p.has_goal; d.m = p.max_corrections;
+  d.maxiter = p.max_iterations; d.maxls = p.max_linesearch; d.maxfun = p.max_fun;
+  d.dt = p.dt; d.mass = p.mass; d.grav = p.gravity; d.hover = p.mass * p.gravity;
+  d.wp = p.position_weight; d.wv = p.velocity_weight; d.wa = p.acceleration_weight; d.wT = p.thrust_weight;
+  d.term = p.terminal_factor;
+  d.pos_b = p.position_bound; d.v_max = p.max_velocity; d.txy = p.max_thrust * sin(p.max_tilt_angle);
+  d.tz_lo = p.min_thrust; d.tz_hi = p.max_thrust;
+  d.pgtol = p.pgtol; d.ftol = p.ftol;
+  return d;
+}
+
+// per-element code: bits 0-1 block (0 P, 1 V, 2 T, 3 padding), bits 2-3 axis, bit 4 terminal P row
+__device__ __forceinline__ int elem_code(const SolveDev& q, int i) {
+  if (i >= q.n) return 3;
+  const int n3 = 3 * q.N;
+  const int blk = i / n3, r = i - blk * n3, k = r / 3, a = r - 3 * k;
+  return blk | (a << 2) | ((blk == 0 && k == q.N - 1) ? 16 : 0);
+}
+__device__ __forceinline__ void elem_bounds(const SolveDev& q, int code, double& lo, double& hi) {
+  const int blk = code & 3, a = (code >> 2) & 3;
+  if (blk == 0) { lo = -q.pos_b; hi = q.pos_b; }
+  else if (blk == 1) { lo = -q.v_max; hi = q.v_max; }
+  else if (blk == 2) { if (a == 2) { lo = q.tz_lo; hi = q.tz_hi; } else { lo = -q.txy; hi = q.txy; } }
+  else { lo = 0.0; hi = 0.0; }
+}
+
+// Moré-Thuente safeguarded step (MINPACK-2 dcstep).
+__device__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
+                       double fp, double dp, bool& brackt, double stpmin, double stpmax) {
+  const double sgnd = dp * (dx / fabs(dx));
+  double stpf;
+  if (fp > fx) {
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp < stx) gamma = -gamma;
+    const double p = (gamma - dx) + theta, qq = ((gamma - dx) + gamma) + dp, r = p / qq;
+    const double stpc = stx + r * (stp - stx);
+    const double stpq = stx + ((dx / ((fx - fp) / (stp - stx) + dx)) / 2.0) * (stp - stx);
+    stpf = (fabs(stpc - stx) < fabs(stpq - stx)) ? stpc : stpc + (stpq - stpc) / 2.0;
+    brackt = true;
+  } else if (sgnd < 0.0) {
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = s * sqrt((theta / s) * (theta / s) - (dx / s) * (dp / s));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta, qq = ((gamma - dp) + gamma) + dx, r = p / qq;
+    const double stpc = stp + r * (stx - stp);
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    stpf = (fabs(stpc - stp) > fabs(stpq - stp)) ? stpc : stpq;
+    brackt = true;
+  } else if (fabs(dp) < fabs(dx)) {
+    const double theta = 3.0 * (fx - fp) / (stp - stx) + dx + dp;
+    const double s = fmax(fabs(theta), fmax(fabs(dx), fabs(dp)));
+    double gamma = s * sqrt(fmax(0.0, (theta / s) * (theta / s) - (dx / s) * (dp / s)));
+    if (stp > stx) gamma = -gamma;
+    const double p = (gamma - dp) + theta, qq = (gamma + (dx - dp)) + gamma, r = p / qq;
+    double stpc;
+    if (r < 0.0 && gamma != 0.0) stpc = stp + r * (stx - stp);
+    else if (stp > stx) stpc = stpmax;
+    else stpc = stpmin;
+    const double stpq = stp + (dp / (dp - dx)) * (stx - stp);
+    if (brackt) {
+      stpf = (fabs(stpc - stp) < fabs(stpq - stp)) ? stpc : stpq;
+      if (stp > stx) stpf = fmin(stp + 0.66 * (sty - stp), stpf);
+      else stpf = fmax(stp + 0.66 * (sty - stp), stpf);
+    } else {
+      stpf = (fabs(stpc - stp) > fabs(stpq - stp)) ? stpc : stpq;
+      stpf = fmin(stpmax, stpf);
+      stpf = fmax(stpmin, stpf);
+    }
+  } else {
+    if (brackt) {
+      const double theta = 3.0 * (fp - fy) / (sty - stp) + dy + dp;
+      const double s = fmax(fabs(theta), fmax(fabs(dy), fabs(dp)));
+      double gamma = s * sqrt((theta / s) * (theta / s) - (dy / s) * (dp / s));
+      if (stp > sty) gamma = -gamma;
+      const double p = (gamma - dp) + theta, qq = ((gamma - dp) + gamma) + dy, r = p / qq;
+      stpf = stp + r * (sty - stp);
+    } else if (stp > stx) stpf = stpmax;
+    else stpf = stpmin;
+  }
+  if (fp > fx) { sty = stp; fy = fp; dy = dp; }
+  else {
+    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
+    stx = stp; fx = fp; dx = dp;
+  }
+  stp = stpf;
+}
+
+// State of one line search (dcsrch's isave/dsave); every lane holds an identical copy.
+struct LineSearch {
+  bool brackt; int stage;
+  double ginit, gtest, gx, gy, finit, fx, fy, stx, sty, stmin, stmax, width, width1;
+};
+enum { LS_FG = 0, LS_CONV = 1, LS_WARN = 2, LS_ERROR = 3 };
+
+__device__ int dcsrch(double f, double g, double& stp, double stpmin, double stpmax, bool start, LineSearch& s) {
+  const double ftol = 1.0e-3, gtol = 0.9, xtol = 0.1, xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
+  if (start) {
+    if (stp < stpmin || stp > stpmax || g >= 0.0 || stpmax < stpmin) return LS_ERROR;
+    s.brackt = false; s.stage = 1; s.finit = f; s.ginit = g; s.gtest = ftol * g;
+    s.width = stpmax - stpmin; s.width1 = s.width / p5;
+    s.stx = 0.0; s.fx = f; s.gx = g; s.sty = 0.0; s.fy = f; s.gy = g;
+    s.stmin = 0.0; s.stmax = stp + xtrapu * stp;
+    return LS_FG;
+  }
+  const double ftest = s.finit + stp * s.gtest;
+  if (s.stage == 1 && f <= ftest && g >= 0.0) s.stage = 2;
+  int task = LS_FG;
+  if (s.brackt && (stp <= s.stmin || stp >= s.stmax)) task = LS_WARN;
+  if (s.brackt && s.stmax - s.stmin <= xtol * s.stmax) task = LS_WARN;
+  if (stp == stpmax && f <= ftest && g <= s.gtest) task = LS_WARN;
+  if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;
+  if (f <= ftest && fabs(g) <= gtol * (-s.ginit)) task = LS_CONV;
+  if (task != LS_FG) return task;
+  if (s.stage == 1 && f <= s.fx && f > ftest) {
+    const double fm = f - stp * s.gtest;
+    double fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
+    const double gm = g - s.gtest;
+    double gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
+    dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
+    s.fx = fxm + s.stx * s.gtest; s.fy = fym + s.sty * s.gtest;
+    s.gx = gxm + s.gtest; s.gy = gym + s.gtest;
+  } else {
+    dcstep(s.stx, s.fx, s.gx, s.sty, s.fy, s.gy, stp, f, g, s.brackt, s.stmin, s.stmax);
+  }
+  if (s.brackt) {
+    if (fabs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
+    s.width1 = s.width; s.width = fabs(s.sty - s.stx);
+  }
+  if (s.brackt) { s.stmin = fmin(s.stx, s.sty); s.stmax = fmax(s.stx, s.sty); }
+  else { s.stmin = stp + xtrapl * (stp - s.stx); s.stmax = stp + xtrapu * (stp - s.stx); }
+  stp = fmax(stp, stpmin);
+  stp = fmin(stp, stpmax);
+  if ((s.brackt && (stp <= s.stmin || stp >= s.stmax)) || (s.brackt && s.stmax - s.stmin <= xtol * s.stmax)) stp = s.stx;
+  return LS_FG;
+}
+
+// ---- scalar sections (lane 0 only, operands in LDS) ------------------------------------------
+// LINPACK dpofa on the leading n x n block of a (row stride ld): upper factor in the upper triangle.
+__device__ int dpofa(double* a, int ld, int n) {
+  for (int j = 0; j < n; ++j) {
+    double s = 0.0;
+    for (int k = 0; k < j; ++k) {
+      double t = a[k * ld + j];
+      for (int i = 0; i < k; ++i) t -= a[i * ld + k] * a[i * ld + j];
+      t = t / a[k * ld + k];
+      a[k * ld + j] = t;
+      s += t * t;
+    }
+    s = a[j * ld + j] - s;
+    if (s <= 0.0) return j + 1;
+    a[j * ld + j] = sqrt(s);
+  }
+  return 0;
+}
+// LINPACK dtrsl, t upper triangular (row stride ld): transposed ? t' x = b : t x = b, in place.
+__device__ int dtrsl_upper(const double* t, int ld, int n, double* b, int bstride, bool transposed) {
+  for (int j = 0; j < n; ++j) if (t[j * ld + j] == 0.0) return j + 1;
+  if (!transposed) {
+    b[(n - 1) * bstride] = b[(n - 1) * bstride] / t[(n - 1) * ld + (n - 1)];
+    for (int j = n - 2; j >= 0; --j) {
+      const double temp = -b[(j + 1) * bstride];
+      for (int i = 0; i <= j; ++i) b[i * bstride] += temp * t[i * ld + (j + 1)];
+      b[j * bstride] = b[j * bstride] / t[j * ld + j];
+    }
+  } else {
+    b[0] = b[0] / t[0];
+    for (int j = 1; j < n; ++j) {
+      double s = b[j * bstride];
+      for (int i = 0; i < j; ++i) s -= t[i * ld + j] * b[i * bstride];
+      b[j * bstride] = s / t[j * ld + j];
+    }
+  }
+  return 0;
+}
+// bmv: p = M v for the 2col x 2col middle matrix (sy, wt with row stride m).
+__device__ int bmv(const double* sy, const double* wt, int m, int col, const double* v, double* p) {
+  if (col == 0) return 0;
+  p[col] = v[col];
+  for (int i = 1; i < col; ++i) {
+    double s = 0.0;
+    for (int k = 0; k < i; ++k) s += sy[i * m + k] * v[k] / sy[k * m + k];
+    p[col + i] = v[col + i] + s;
+  }
+  int info = dtrsl_upper(wt, m, col, p + col, 1, true);
+  if (info) return info;
+  for (int i = 0; i < col; ++i) p[i] = v[i] / sqrt(sy[i * m + i]);
+  info = dtrsl_upper(wt, m, col, p + col, 1, false);
+  if (info) return info;
+  for (int i = 0; i < col; ++i) p[i] = -p[i] / sqrt(sy[i * m + i]);
+  for (int i = 0; i < col; ++i) {
+    double s = 0.0;
+    for (int k = i + 1; k < col; ++k) s += sy[k * m + i] * p[col + k] / sy[i * m + i];
+    p[i] += s;
+  }
+  return 0;
+}
+
+// ---- the solver ------------------------------------------------------------------------------
+template <typename IO, int J>
+__global__ void __launch_bounds__(64)
+solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict__ v0g, const IO* __restrict__ goalg,
+             const IO* __restrict__ x0g, IO* __restrict__ Xg, se3mpc_solve_info* __restrict__ infog,
+             IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg) {
+  HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  const int lane = lane_id();
+  const int pb = blockIdx.x;               // problem index
+  const int n = q.n, N = q.N, m = q.m, npad = kWave * J;
+  // LDS carve-up: doubles first, then the S / Y pairs in the IO type
+  double* sy = reinterpret_cast<double*>(lds_raw);     // [m][m]  S'Y (lower triangle used)
+  double* ss = sy + m * m;                             // [m][m]  S'S (upper triangle used)
+  double* wt = ss + m * m;                             // [m][m]  Cholesky factor of theta*S'S + L D^-1 L'
+  double* wn = wt + m * m;                             // [2m][2m] LEL' factor of the subspace K matrix
+  double* pv = wn + 4 * m * m;                         // [2m]  p = W'd            (Cauchy)
+  double* cv = pv + 2 * m;                             // [2m]  c = W'(xcp - x)    (Cauchy)
+  double* vv = cv + 2 * m;                             // [2m]  scratch M*...
+  double* wbp = vv + 2 * m;                            // [2m]  row of W at a breakpoint
+  double* wv = wbp + 2 * m;                            // [2m]  subspace rhs
+  double* sc = wv + 2 * m;                             // [8]   scalars handed out of scalar sections
+  IO* ws = reinterpret_cast<IO*>(sc + 8);              // [m][npad]
+  IO* wy = ws + m * npad;                              // [m][npad]
+  double* scratch = reinterpret_cast<double*>(ws);     // reused after the solve (needs 12*64 doubles <= 2*m*npad*sizeof(IO))
+
+  // ---- per-element constants and problem data
+  int code[J];
+  double x[J], g[J], z[J], d[J], xo[J], go[J];
+  const double goal0 = q.has_goal ? (double)goalg[pb * 3 + 0] : 0.0;
+  const double goal1 = q.has_goal ? (double)goalg[pb * 3 + 1] : 0.0;
+  const double goal2 = q.has_goal ? (double)goalg[pb * 3 + 2] : 0.0;
+  auto goal_of = [&](int cd) { const int a = (cd >> 2) & 3; return a == 0 ? goal0 : (a == 1 ? goal1 : goal2); };
+
+  // ---- cold start (planner.py:329-359) or caller x0, projected into the box (L-BFGS-B `active`)
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = lane + kWave * j;
+    code[j] = elem_code(q, i);
+    double lo, hi;
+    elem_bounds(q, code[j], lo, hi);
+    double xv = 0.0;
+    const int blk = code[j] & 3, a = (code[j] >> 2) & 3;
+    if (blk != 3) {
+      if (x0g != nullptr) {
+        xv = (double)x0g[(size_t)pb * n + i];
+      } else {
+        const int r = i - blk * 3 * N, k = r / 3;
+        const double pa = (double)p0g[pb * 3 + a], va = (double)v0g[pb * 3 + a], ga = goal_of(code[j]);
+        const double denom = (double)(N - 1 > 1 ? N - 1 : 1);
+        if (blk == 0) {
+          const double alpha = (double)k / denom;
+          xv = q.has_goal ? (1.0 - alpha) * pa + alpha * ga : pa;
+        } else if (blk == 1) {
+          if (k == 0) xv = va;
+          else if (q.has_goal) {
+            const double a1 = (double)k / denom, a0 = (double)(k - 1) / denom;
+            xv = (((1.0 - a1) * pa + a1 * ga) - ((1.0 - a0) * pa + a0 * ga)) / q.dt;
+          } else xv = 0.0;
+        } else {
+          xv = (a == 2) ? q.hover : 0.0;
+        }
+      }
+    }
+    x[j] = fmin(fmax(xv, lo), hi);
+    g[j] = 0.0; z[j] = x[j]; d[j] = 0.0; xo[j] = x[j]; go[j] = 0.0;
+  }
+
+  // objective (planner.py:516-550) and the reference's gradient (planner.py:552-580) at x
+  auto eval_fg = [&]() -> double {
+    double part = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      const int blk = code[j] & 3, a = (code[j] >> 2) & 3;
+      const double xv = x[j];
+      double fj = 0.0, gj = 0.0;
+      if (blk == 0) {
+        if (q.has_goal) {
+          const double e = xv - goal_of(code[j]);
+          fj = q.wp * (e * e);
+          if (code[j] & 16) fj += q.term * q.wp * (e * e);
+          gj = 2.0 * q.wp * e;
+        }
+      } else if (blk == 1) {
+        fj = q.wv * (xv * xv); gj = 2.0 * q.wv * xv;
+      } else if (blk == 2) {
+        const double ac = xv / q.mass - (a == 2 ? q.grav : 0.0);
+        const double dv = xv - (a == 2 ? q.hover : 0.0);
+        fj = q.wa * (ac * ac) + q.wT * (dv * dv);
+        gj = 2.0 * q.wT * xv;
+      }
+      part += fj;
+      g[j] = gj;
+    }
+    return wave_sum(part);
+  };
+  // projected gradient norm (projgr)
+  auto projgr = [&]() -> double {
+    double mx = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+      double lo, hi;
+      elem_bounds(q, code[j], lo, hi);
+      double gi = g[j];
+      if ((code[j] & 3) == 3) gi = 0.0;
+      else if (gi < 0.0) gi = fmax(x[j] - hi, gi);
+      else gi = fmin(x[j] - lo, gi);
+      mx = fmax(mx, fabs(gi));
+    }
+    return wave_max(mx);
+  };
+  auto WS = [&](int c, int j) -> IO& { return ws[c * npad + lane + kWave * j]; };
+  auto WY = [&](int c, int j) -> IO& { return wy[c * npad + lane + kWave * j]; };
+
+  // ---- L-BFGS-B state (identical in every lane)
+  int col = 0, iupdat = 0, iter = 0, nit = 0, nfev = 0;
+  double theta = 1.0;
+  int iwhere[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) iwhere[j] = ((code[j] & 3) == 3) ? 3 : 0;   // padding = fixed variables
+  double f = eval_fg();
+  nfev = 1;
+  double sbgnrm = projgr();
+  int status = 0, task = 0;
+  double fold = f;
+
+  if (sbgnrm <= q.pgtol) { task = SE3MPC_TASK_CONV_PGTOL; status = 0; }
+
+  int guard = 0;                           // every pass either ends an iteration or drops the memory; bounded anyway
+  while (task == 0) {
+    if (++guard > 4 * (q.maxiter + 8)) { task = SE3MPC_TASK_ABNORMAL; status = 2; break; }
+    // ===================================================================== Cauchy point
+    int info = 0;
+    {
+      // pass 1: search direction d = -g on the free variables, breakpoints, p = W'd, f1 = -d'd
+      double tbp[J];
+      double f1p = 0.0;
+      int nbr = 0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double lo, hi;
+        elem_bounds(q, code[j], lo, hi);
+        const double neggi = -g[j];
+        tbp[j] = kInf;
+        double tl = 0.0, tu = 0.0;
+        if (iwhere[j] != 3) {
+          tl = x[j] - lo; tu = hi - x[j];
+          const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
+          iwhere[j] = 0;
+          if (xlower) { if (neggi <= 0.0) iwhere[j] = 1; }
+          else if (xupper) { if (neggi >= 0.0) iwhere[j] = 2; }
+          else if (fabs(neggi) <= 0.0) iwhere[j] = -3;
+        }
+        if (iwhere[j] != 0) {
+          d[j] = 0.0;
+        } else {
+          d[j] = neggi;
+          f1p -= neggi * neggi;
+          if (neggi < 0.0) { tbp[j] = tl / (-neggi); ++nbr; }
+          else if (neggi > 0.0) { tbp[j] = tu / neggi; ++nbr; }
+        }
+        z[j] = x[j];
+      }
+      double f1 = wave_sum(f1p);
+      const int nbreak = wave_sum_i32(nbr);
+      // p = W'd (2col wavefront reductions), second half scaled by theta
+      for (int c = 0; c < col; ++c) {
+        double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+        a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) { pv[c] = a1; pv[col + c] = theta * a2; cv[c] = 0.0; cv[col + c] = 0.0; }
+      }
+      __syncthreads();
+      if (sbgnrm > 0.0 && nbreak > 0) {
+        double f2 = -theta * f1;
+        const double f2_org = f2;
+        if (col > 0) {
+          if (lane == 0) {
+            const int inf = bmv(sy, wt, m, col, pv, vv);
+            double dot = 0.0;
+            for (int i = 0; i < 2 * col; ++i) dot += vv[i] * pv[i];
+            sc[0] = dot; sc[1] = (double)inf;
+          }
+          __syncthreads();
+          info = (int)sc[1];
+          f2 -= sc[0];
+          __syncthreads();
+        }
+        if (info == 0) {
+          double dtm = -f1 / f2, tsum = 0.0, tj = 0.0;
+          int nleft = nbreak;
+          bool all_fixed = false;
+          while (nleft > 0) {
+            // next smallest breakpoint: per-lane min, DPP min, owner = first lane holding it
+            double tmin = tbp[0];
+            int jm = 0;
+#pragma unroll
+            for (int j = 1; j < J; ++j) if (tbp[j] < tmin) { tmin = tbp[j]; jm = j; }
+            const double tj0 = tj;
+            tj = wave_min(tmin);
+            const int src = first_lane(wave_ballot(tmin == tj));
+            if (src < 0) { info = 1; break; }                 // NaN breakpoints: give up on this memory
+            const int jsel = wave_bcast(jm, src);
+            const double dt = tj - tj0;
+            if (dtm < dt) break;
+            tsum += dt;
+            --nleft;
+            // owner fixes its variable at the bound it hits
+            double dib = 0.0, zib = 0.0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+              if (j == jsel && lane == src) {
+                double lo, hi;
+                elem_bounds(q, code[j], lo, hi);
+                dib = d[j]; d[j] = 0.0; tbp[j] = kInf;
+                if (dib > 0.0) { zib = hi - x[j]; z[j] = hi; iwhere[j] = 2; }
+                else { zib = lo - x[j]; z[j] = lo; iwhere[j] = 1; }
+              }
+            }
+            const double dibp = wave_bcast(dib, src), zibp = wave_bcast(zib, src);
+            if (nleft == 0 && nbreak == n) { dtm = dt; all_fixed = true; break; }
+            const double dibp2 = dibp * dibp;
+            f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
+            f2 = f2 - theta * dibp2;
+            if (col > 0) {
+              const int ibp = src + kWave * jsel;
+              if (lane == 0) {
+                for (int i = 0; i < 2 * col; ++i) cv[i] += dt * pv[i];
+                for (int c = 0; c < col; ++c) { wbp[c] = (double)wy[c * npad + ibp]; wbp[col + c] = theta * (double)ws[c * npad + ibp]; }
+                const int inf = bmv(sy, wt, m, col, wbp, vv);
+                double wmc = 0.0, wmp = 0.0, wmw = 0.0;
+                for (int i = 0; i < 2 * col; ++i) { wmc += cv[i] * vv[i]; wmp += pv[i] * vv[i]; wmw += wbp[i] * vv[i]; }
+                for (int i = 0; i < 2 * col; ++i) pv[i] -= dibp * wbp[i];
+                sc[0] = wmc; sc[1] = wmp; sc[2] = wmw; sc[3] = (double)inf;
+              }
+              __syncthreads();
+              info = (int)sc[3];
+              f1 += dibp * sc[0];
+              f2 += 2.0 * dibp * sc[1] - dibp2 * sc[2];
+              __syncthreads();
+              if (info != 0) break;
+            }
+            f2 = fmax(kEps * f2_org, f2);
+            if (nleft > 0) dtm = -f1 / f2;
+            else { f1 = 0.0; f2 = 0.0; dtm = 0.0; }       // every variable with d != 0 has hit a bound
+          }
+          if (info == 0) {
+            if (!all_fixed) {
+              if (dtm <= 0.0) dtm = 0.0;
+              tsum += dtm;
+#pragma unroll
+              for (int j = 0; j < J; ++j) z[j] += tsum * d[j];
+            }
+            if (col > 0) {
+              if (lane == 0) for (int i = 0; i < 2 * col; ++i) cv[i] += dtm * pv[i];
+              __syncthreads();
+            }
+          }
+        }
+      }
+    }
+    if (info != 0) { col = 0; theta = 1.0; iupdat = 0; continue; }   // singular middle matrix: refresh memory
+
+    // ===================================================================== subspace minimization
+    int nfree_p = 0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) nfree_p += (iwhere[j] <= 0) ? 1 : 0;
+    const int nfree = wave_sum_i32(nfree_p);
+    if (nfree != 0 && col != 0) {
+      // ---- formk: K blocks from inner products over the free (Z) and active (A) sets
+      for (int iy = 0; iy < col; ++iy) {
+        for (int jy = 0; jy < col; ++jy) {
+          double yzzy = 0.0, saas = 0.0, sa_y = 0.0, sz_y = 0.0;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            const bool fr = iwhere[j] <= 0;
+            const double wyi = (double)WY(iy, j), wyj = (double)WY(jy, j), wsi = (double)WS(iy, j), wsj = (double)WS(jy, j);
+            if (fr) { yzzy += wyi * wyj; sz_y += wsi * wyj; }
+            else { saas += wsi * wsj; sa_y += wsi * wyj; }     // active set (padding rows of S, Y are zero)
+          }
+          // wn (upper triangle, row stride 2m):  [ D + Y'ZZ'Y/theta   -L_a' + R_z' ;  .   theta S'AA'S ]
+          if (jy <= iy) {
+            yzzy = wave_sum(yzzy); saas = wave_sum(saas);
+            if (lane == 0) {
+              wn[jy * 2 * m + iy] = yzzy / theta + (jy == iy ? sy[iy * m + iy] : 0.0);
+              wn[(col + jy) * 2 * m + (col + iy)] = saas * theta;
+            }
+          }
+          if (jy < iy) {
+            sa_y = wave_sum(sa_y);
+            if (lane == 0) wn[jy * 2 * m + (col + iy)] = -sa_y;
+          } else {
+            sz_y = wave_sum(sz_y);
+            if (lane == 0) wn[jy * 2 * m + (col + iy)] = sz_y;
+          }
+        }
+      }
+      __syncthreads();
+      if (lane == 0) {
+        const int ld = 2 * m;
+        int inf = dpofa(wn, ld, col);
+        if (inf) inf = -1;
+        else {
+          for (int js = col; js < 2 * col; ++js) dtrsl_upper(wn, ld, col, wn + js, ld, true);
+          for (int is = col; is < 2 * col; ++is)
+            for (int js = is; js < 2 * col; ++js) {
+              double s = 0.0;
+              for (int k = 0; k < col; ++k) s += wn[k * ld + is] * wn[k * ld + js];
+              wn[is * ld + js] += s;
+            }
+          if (dpofa(wn + col * ld + col, ld, col)) inf = -2;
+        }
+        // ---- cmprlb, scalar part: mc = M c
+        if (inf == 0 && bmv(sy, wt, m, col, cv, vv)) inf = -8;
+        sc[0] = (double)inf;
+      }
+      __syncthreads();
+      info = (int)sc[0];
+      if (info == 0) {
+        // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
+#pragma unroll
+        for (int j = 0; j < J; ++j) d[j] = (iwhere[j] <= 0) ? (-theta * (z[j] - x[j]) - g[j]) : 0.0;
+        for (int c = 0; c < col; ++c) {
+          const double a1 = vv[c], a2 = theta * vv[col + c];
+#pragma unroll
+          for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * a1 + (double)WS(c, j) * a2;
+        }
+        // ---- subsm: wv = W'Z d ; wv = K^-1 wv ; d = (d + Z'W wv-ish)/theta
+        for (int c = 0; c < col; ++c) {
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+          a1 = wave_sum(a1); a2 = wave_sum(a2);
+          if (lane == 0) { wv[c] = a1; wv[col + c] = theta * a2; }
+        }
+        __syncthreads();
+        if (lane == 0) {
+          int inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, true);
+          if (!inf) {
+            for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+            inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, false);
+          }
+          sc[0] = (double)inf;
+        }
+        __syncthreads();
+        info = (int)sc[0];
+        if (info == 0) {
+          for (int c = 0; c < col; ++c) {
+            const double b1 = wv[c] / theta, b2 = wv[col + c];
+#pragma unroll
+            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * b1 + (double)WS(c, j) * b2;
+          }
+          const double rth = 1.0 / theta;
+          // projected Newton point; xo/go are free here (the line search re-saves them): xo keeps xcp
+          bool hitp = false;
+          double ddp = 0.0;
+#pragma unroll
+          for (int j = 0; j < J; ++j) {
+            xo[j] = z[j];
+            if (iwhere[j] <= 0) {
+              d[j] *= rth;
+              double lo, hi;
+              elem_bounds(q, code[j], lo, hi);
+              const double xk = fmin(hi, fmax(lo, z[j] + d[j]));
+              z[j] = xk;
+              if (xk == lo || xk == hi) hitp = true;
+            }
+            ddp += (z[j] - x[j]) * g[j];
+          }
+          const bool iword = wave_ballot(hitp) != 0ull;
+          if (iword) {
+            const double dd_p = wave_sum(ddp);
+            if (dd_p > 0.0) {
+              // not a descent direction: back to xcp and truncate the Newton step at the first bound
+              double amin = 1.0;
+              unsigned imin = 0xFFFFFFFFu;
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                z[j] = xo[j];
+                if (iwhere[j] <= 0) {
+                  double lo, hi;
+                  elem_bounds(q, code[j], lo, hi);
+                  const double dk = d[j];
+                  double cand = 1.0;
+                  if (dk < 0.0) { const double t2 = lo - z[j]; cand = (t2 >= 0.0) ? 0.0 : ((dk * 1.0 < t2) ? t2 / dk : 1.0); }
+                  else if (dk > 0.0) { const double t2 = hi - z[j]; cand = (t2 <= 0.0) ? 0.0 : ((dk * 1.0 > t2) ? t2 / dk : 1.0); }
+                  if (cand < amin) { amin = cand; imin = (unsigned)(lane + kWave * j); }
+                }
+              }
+              const double alpha = wave_min(amin);
+              const unsigned ibd = wave_min_u32(amin == alpha && alpha < 1.0 ? imin : 0xFFFFFFFFu);
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                if (iwhere[j] <= 0) {
+                  if (alpha < 1.0 && (unsigned)(lane + kWave * j) == ibd) {
+                    double lo, hi;
+                    elem_bounds(q, code[j], lo, hi);
+                    if (d[j] > 0.0) { z[j] = hi; d[j] = 0.0; }
+                    else if (d[j] < 0.0) { z[j] = lo; d[j] = 0.0; }
+                  }
+                  z[j] += alpha * d[j];
+                }
+              }
+            }
+          }
+        }
+      }
+      if (info != 0) { col = 0; theta = 1.0; iupdat = 0; continue; }
+    }
+
+    // ===================================================================== line search (lnsrlb)
+    double dtdp = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { d[j] = z[j] - x[j]; dtdp += d[j] * d[j]; }
+    const double dtd = wave_sum(dtdp);
+    double stpmx;
+    if (iter == 0) stpmx = 1.0;
+    else {
+      double smx = kBig;
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        double lo, hi;
+        elem_bounds(q, code[j], lo, hi);
+        const double a1 = d[j];
+        if (a1 < 0.0) { const double a2 = lo - x[j]; if (a2 >= 0.0) smx = 0.0; else if (a1 * smx < a2) smx = a2 / a1; }
+        else if (a1 > 0.0) { const double a2 = hi - x[j]; if (a2 <= 0.0) smx = 0.0; else if (a1 * smx > a2) smx = a2 / a1; }
+      }
+      stpmx = wave_min(smx);
+    }
+    double stp = 1.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { xo[j] = x[j]; go[j] = g[j]; }
+    fold = f;
+    int ifun = 0, iback = 0, ls_info = 0;
+    double gd = 0.0, gdold = 0.0;
+    LineSearch ls;
+    bool start = true;
+    while (true) {
+      double gdp = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) gdp += g[j] * d[j];
+      gd = wave_sum(gdp);
+      if (ifun == 0) {
+        gdold = gd;
+        if (gd >= 0.0) { ls_info = -4; break; }
+      }
+      const int lt = dcsrch(f, gd, stp, 0.0, stpmx, start, ls);
+      start = false;
+      if (lt == LS_CONV || lt == LS_WARN) break;
+      if (lt == LS_ERROR) { ls_info = -4; break; }          // dcsrch rejected its inputs (never with a feasible d)
+      ++ifun; ++nfev; iback = ifun - 1;
+      if (iback >= q.maxls) break;
+      if (stp == 1.0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) x[j] = z[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < J; ++j) x[j] = stp * d[j] + xo[j];
+      }
+      f = eval_fg();
+    }
+    if (ls_info != 0 || iback >= q.maxls) {
+      // restore the previous iterate
+#pragma unroll
+      for (int j = 0; j < J; ++j) { x[j] = xo[j]; g[j] = go[j]; }
+      f = fold;
+      if (ls_info == 0) --nfev;
+      if (col == 0) { task = SE3MPC_TASK_ABNORMAL; status = 2; break; }
+      col = 0; theta = 1.0; iupdat = 0;
+      continue;
+    }
+
+    // ===================================================================== new iterate
+    ++iter; ++nit;
+    sbgnrm = projgr();
+    if (nit >= q.maxiter) { task = SE3MPC_TASK_STOP_MAXITER; status = 1; break; }
+    if (nfev > q.maxfun) { task = SE3MPC_TASK_STOP_MAXFUN; status = 1; break; }
+    if (sbgnrm <= q.pgtol) { task = SE3MPC_TASK_CONV_PGTOL; status = 0; break; }
+    {
+      const double ddum = fmax(fabs(fold), fmax(fabs(f), 1.0));
+      if ((fold - f) <= q.ftol * ddum) { task = SE3MPC_TASK_CONV_FTOL; status = 0; break; }
+    }
+    // ---- BFGS update (matupd + formt)
+    double rrp = 0.0;
+#pragma unroll
+    for (int j = 0; j < J; ++j) { go[j] = g[j] - go[j]; rrp += go[j] * go[j]; }   // go = y
+    const double rr = wave_sum(rrp);
+    double dr, ddum;
+    if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
+    else {
+      dr = (gd - gdold) * stp; ddum = -gdold * stp;
+#pragma unroll
+      for (int j = 0; j < J; ++j) d[j] *= stp;
+    }
+    if (dr <= kEps * ddum) continue;                    // skip the update
+    ++iupdat;
+    if (iupdat <= m) col = iupdat;
+    else {
+      // memory full: drop the oldest pair (each lane shifts its own elements; lane 0 the small matrices)
+      for (int c = 0; c + 1 < m; ++c) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) { WS(c, j) = WS(c + 1, j); WY(c, j) = WY(c + 1, j); }
+      }
+      if (lane == 0)
+        for (int i = 0; i + 1 < m; ++i)
+          for (int k = 0; k + 1 < m; ++k) { ss[i * m + k] = ss[(i + 1) * m + k + 1]; sy[i * m + k] = sy[(i + 1) * m + k + 1]; }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < J; ++j) { WS(col - 1, j) = (IO)d[j]; WY(col - 1, j) = (IO)go[j]; }
+    theta = rr / dr;
+    for (int c = 0; c + 1 < col; ++c) {
+      double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
+      a1 = wave_sum(a1); a2 = wave_sum(a2);
+      if (lane == 0) { sy[(col - 1) * m + c] = a1; ss[c * m + (col - 1)] = a2; }
+    }
+    if (lane == 0) {
+      ss[(col - 1) * m + (col - 1)] = (stp == 1.0) ? dtd : stp * stp * dtd;
+      sy[(col - 1) * m + (col - 1)] = dr;
+      // formt: T = theta*S'S + L D^-1 L', Cholesky factor in wt
+      for (int jj = 0; jj < col; ++jj) wt[jj] = theta * ss[jj];
+      for (int i = 1; i < col; ++i)
+        for (int jj = i; jj < col; ++jj) {
+          const int k1 = i < jj ? i : jj;
+          double dd = 0.0;
+          for (int k = 0; k < k1; ++k) dd += sy[i * m + k] * sy[jj * m + k] / sy[k * m + k];
+          wt[i * m + jj] = dd + theta * ss[i * m + jj];
+        }
+      sc[0] = (double)dpofa(wt, m, col);
+    }
+    __syncthreads();
+    if (sc[0] != 0.0) { col = 0; theta = 1.0; iupdat = 0; }
+    __syncthreads();
+  }
+
+  // ===================================================================== results
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = lane + kWave * j;
+    if (i < n) Xg[(size_t)pb * n + i] = (IO)x[j];
+  }
+  if (lane == 0 && infog != nullptr) {
+    se3mpc_solve_info r;
+    r.fun = f; r.nit = nit; r.nfev = nfev; r.status = status; r.task = task;
+    infog[pb] = r;
+  }
+  // ---- _extract_solution_from_result (planner.py:582-654): T block -> LDS, lane k = step k
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = lane + kWave * j;
+    if ((code[j] & 3) == 2) {
+      const int r = i - 6 * N;
+      scratch[r] = x[j];
+      if (accg != nullptr) accg[(size_t)pb * 3 * N + r] = (IO)(x[j] / q.mass - (((code[j] >> 2) & 3) == 2 ? q.grav : 0.0));
+    }
+  }
+  __syncthreads();
+  double* Rm = scratch + 3 * kWave;       // [9][64]: b1, b2, b3 of every step
+  const bool have = lane < N;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  if (have) { t0 = scratch[3 * lane]; t1 = scratch[3 * lane + 1]; t2 = scratch[3 * lane + 2]; }
+  const double mag = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+  const bool valid = have && mag > 1e-6;
+  double b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+  double roll = 0.0, pitch = 0.0, yaw = 0.0;
+  if (valid) {
+    b3[0] = t0 / mag; b3[1] = t1 / mag; b3[2] = t2 / mag;
+    b1[0] = 0.0; b1[1] = -b3[2]; b1[2] = b3[1];
+    const double n1 = sqrt(b1[1] * b1[1] + b1[2] * b1[2]);
+    if (n1 > 1e-6) { b1[1] /= n1; b1[2] /= n1; } else { b1[0] = 1.0; b1[1] = 0.0; b1[2] = 0.0; }
+    b2[0] = b3[1] * b1[2] - b3[2] * b1[1];
+    b2[1] = b3[2] * b1[0] - b3[0] * b1[2];
+    b2[2] = b3[0] * b1[1] - b3[1] * b1[0];
+    roll = atan2(b2[2], b3[2]);
+    pitch = asin(fmin(fmax(-b1[2], -1.0), 1.0));
+    yaw = atan2(b1[1], b1[0]);
+  }
+  for (int c = 0; c < 3; ++c) { Rm[c * kWave + lane] = b1[c]; Rm[(3 + c) * kWave + lane] = b2[c]; Rm[(6 + c) * kWave + lane] = b3[c]; }
+  __syncthreads();
+  // prev_R of step k = R of the nearest earlier step with |T| > 1e-6 (planner.py:641-650)
+  const uint64_t vmask = wave_ballot(valid);
+  const uint64_t below = vmask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+  if (valid && below != 0ull) {
+    const int pk = 63 - __builtin_clzll(below);
+    const double inv_dt = 1.0 / q.dt;
+    double d1[3], d2[3], d3[3];
+    for (int c = 0; c < 3; ++c) {
+      d1[c] = (b1[c] - Rm[c * kWave + pk]) / q.dt;
+      d2[c] = (b2[c] - Rm[(3 + c) * kWave + pk]) / q.dt;
+      d3[c] = (b3[c] - Rm[(6 + c) * kWave + pk]) / q.dt;
+    }
+    (void)inv_dt;
+    w0 = b3[0] * d2[0] + b3[1] * d2[1] + b3[2] * d2[2];
+    w1 = b1[0] * d3[0] + b1[1] * d3[1] + b1[2] * d3[2];
+    w2 = b2[0] * d1[0] + b2[1] * d1[1] + b2[2] * d1[2];
+  }
+  if (have) {
+    const size_t o = (size_t)pb * 3 * N + 3 * lane;
+    if (attg != nullptr) { attg[o] = (IO)roll; attg[o + 1] = (IO)pitch; attg[o + 2] = (IO)yaw; }
+    if (ratesg != nullptr) { ratesg[o] = (IO)w0; ratesg[o + 1] = (IO)w1; ratesg[o + 2] = (IO)w2; }
+    if (thrustg != nullptr) thrustg[(size_t)pb * N + lane] = (IO)mag;
+  }
+}
+
+static size_t solve_lds_bytes(int m, int J, size_t io_size) {
+  const size_t doubles = (size_t)3 * m * m + 4 * m * m + 5 * 2 * m + 8;
+  size_t pairs = (size_t)2 * m * kWave * J * io_size;
+  const size_t scratch = (size_t)12 * kWave * sizeof(double);
+  if (pairs < scratch) pairs = scratch;
+  return doubles * sizeof(double) + pairs;
+}
+
+template <typename IO>
+int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const IO* goal, const IO* x0, IO* X,
+               se3mpc_solve_info* info, IO* acc, IO* att, IO* rates, IO* thrust, void* stream) {
+  if (p == nullptr) return SE3MPC_ERR_NULL;
+  int rc = check_params_impl(p);
+  if (rc) return rc;
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!p0 || !v0 || !X || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  const SolveDev q = make_solve_dev(*p);
+  const int n = q.n;
+  const int Jneed = (n + kWave - 1) / kWave;
+  hipStream_t s = (hipStream_t)stream;
+#define SE3MPC_SOLVE_CASE(JJ)                                                                                         \
+  hipLaunchKernelGGL((solve_kernel<IO, JJ>), dim3(B), dim3(kWave), solve_lds_bytes(q.m, JJ, sizeof(IO)), s, q, B, p0, \
+                     v0, goal, x0, X, info, acc, att, rates, thrust)
+  if (Jneed <= 1) SE3MPC_SOLVE_CASE(1);
+  else if (Jneed <= 2) SE3MPC_SOLVE_CASE(2);
+  else if (Jneed <= 3) SE3MPC_SOLVE_CASE(3);
+  else if (Jneed <= 5) SE3MPC_SOLVE_CASE(5);
+  else if (Jneed <= 8) SE3MPC_SOLVE_CASE(8);
+  else SE3MPC_SOLVE_CASE(9);
+#undef SE3MPC_SOLVE_CASE
+  return launch_status("se3mpc_solve");
+}
+
+}  // namespace se3mpc
+
+using namespace se3mpc;
+
+extern "C" int se3mpc_solve_f32(const se3mpc_params* p, int B, const float* p0, const float* v0, const float* goal,
+                                const float* x0, float* X, se3mpc_solve_info* info, float* acc, float* att,
+                                float* rates, float* thrust, void* stream) {
+  return solve_impl<float>(p, B, p0, v0, goal, x0, X, info, acc, att, rates, thrust, stream);
+}
+extern "C" int se3mpc_solve_f64(const se3mpc_params* p, int B, const double* p0, const double* v0, const double* goal,
+                                const double* x0, double* X, se3mpc_solve_info* info, double* acc, double* att,
+                                double* rates, double* thrust, void* stream) {
+  return solve_impl<double>(p, B, p0, v0, goal, x0, X, info, acc, att, rates, thrust, stream);
+}

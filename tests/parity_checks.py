@@ -1,0 +1,232 @@
+"""Parity checks shared by the CPU suite (product kernels compiled for the host, tests/emu) and the
+GPU suite (libse3mpc.so on an MI355X).  Every check drives the C ABI through
+dart_planner_amd.ops.Ops and compares with the oracle (oracle/se3mpc_oracle.py) or with the golden
+vectors produced by the reference itself (tests/golden).
+
+Tolerances (stated once, used everywhere):
+  f64 kernels:  1e-9 absolute/relative on every output (they differ from the reference only by
+                summation order / FMA contraction).
+  f32 kernels:  positions (and every other trajectory array except body rates) <= 1e-4 absolute --
+                the bound BASELINE.json's north_star states ("trajectory position error <= 1e-4 m");
+                costs 5e-6 relative; gradients / residuals 5e-6 of the array's max magnitude;
+                body rates 5e-2 absolute (they are differences of O(1) rotation entries divided by
+                dt = 1/400 s: float32 resolution 6e-8 * 400 * a few terms).
+"""
+import numpy as np
+
+from dart_planner_amd.capi import Params
+from oracle import se3mpc_oracle as orc
+
+F32 = dict(pos=1e-4, cost_rel=5e-6, vec_rel=5e-6, rates=5e-2)
+F64 = dict(pos=1e-9, cost_rel=1e-12, vec_rel=1e-12, rates=1e-7)
+
+
+class Harness:
+    """Backend adaptor: host ndarray <-> backend array."""
+
+    def __init__(self, ops, to_dev, to_host, np_dtype):
+        self.ops, self.to_dev, self.to_host, self.dt = ops, to_dev, to_host, np_dtype
+        self.tol = F32 if np_dtype == np.float32 else F64
+
+    def lane(self, a, B):
+        """(B, ...) host array -> lane layout [rows][B] on the backend."""
+        return self.to_dev(np.ascontiguousarray(np.asarray(a, float).reshape(B, -1).T.astype(self.dt)))
+
+    def prob(self, a):
+        return self.to_dev(np.ascontiguousarray(np.asarray(a, float).astype(self.dt)))
+
+    def unlane(self, a, shape):
+        return self.to_host(a).T.reshape(shape).astype(float)
+
+
+def oracle_cfg(prm: Params) -> orc.OracleConfig:
+    return orc.OracleConfig(prediction_horizon=prm.horizon, dt=prm.dt, max_iterations=prm.max_iterations,
+                            convergence_tolerance=prm.pgtol)
+
+
+def vec_close(a, b, rel, what=""):
+    scale = max(1.0, float(np.max(np.abs(b)))) if np.size(b) else 1.0
+    err = float(np.max(np.abs(np.asarray(a, float) - b))) if np.size(b) else 0.0
+    assert err <= rel * scale, f"{what}: max abs err {err:.3e} > {rel:.1e} * {scale:.3e}"
+
+
+def random_batch(rng, B, N, spread=2.0):
+    cfg = orc.OracleConfig(prediction_horizon=N)
+    p0, v0, goal = rng.uniform(-20, 20, (B, 3)), rng.uniform(-5, 5, (B, 3)), rng.uniform(-20, 20, (B, 3))
+    T = rng.normal(0, spread, (B, N, 3)) + [0, 0, cfg.hover_thrust]
+    return p0, v0, goal, T
+
+
+# --------------------------------------------------------------------------------------- lane kernels
+def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,), dt=None):
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N)
+    if dt is not None:
+        prm.dt = dt
+    cfg = oracle_cfg(prm)
+    t = h.tol
+    p0, v0, goal, T = random_batch(rng, B, N)
+    # a3 / a4
+    X0 = h.unlane(h.ops.init(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B)), (B, 9 * N))
+    ref0 = orc.straight_line_init(p0, v0, goal, cfg)
+    vec_close(X0, ref0, t["vec_rel"] * 10, "init")
+    X0p = h.unlane(h.ops.init(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), project=True), (B, 9 * N))
+    b = orc.bounds(cfg)
+    vec_close(X0p, np.clip(ref0, b[:, 0], b[:, 1]), t["vec_rel"] * 10, "init+project")
+    # a5 / a6 on vectors inside and outside the box
+    X = np.concatenate([rng.uniform(-120, 120, (B, 3 * N)), rng.uniform(-15, 15, (B, 3 * N)), T.reshape(B, -1)], axis=1)
+    f, g = h.ops.cost_grad(prm, h.lane(X, B), h.lane(goal, B))
+    fr = orc.objective(X, goal, cfg)
+    assert np.max(np.abs(h.to_host(f) - fr) / np.abs(fr)) <= t["cost_rel"], "objective"
+    vec_close(h.unlane(g, (B, 9 * N)), orc.gradient(X, goal, cfg), t["vec_rel"], "gradient")
+    # goal_position None (planner.py:524, :546, :567)
+    prm_ng = prm.copy(has_goal=0)
+    f2, g2 = h.ops.cost_grad(prm_ng, h.lane(X, B), None)
+    fr2 = orc.objective(X, None, cfg)
+    assert np.max(np.abs(h.to_host(f2) - fr2) / np.abs(fr2)) <= t["cost_rel"], "objective(no goal)"
+    vec_close(h.unlane(g2, (B, 9 * N)), orc.gradient(X, None, cfg), t["vec_rel"], "gradient(no goal)")
+    # a8
+    R = h.ops.dynamics_residual(prm, h.lane(X, B), h.lane(p0, B), h.lane(v0, B))
+    vec_close(h.unlane(R, (B, 6 * N)), orc.dynamics_residual(X, p0, v0, cfg), t["vec_rel"], "dynamics residual")
+    # a9 (K = 16 as config 3, and the empty table)
+    sph = np.concatenate([np.round(rng.uniform(0, 15, (16, 3)) * 2) / 2, np.ones((16, 1))], axis=1)
+    Cm, cmin, viol = h.ops.obstacle_residual(prm, h.lane(X, B), h.prob(sph))
+    Cref = orc.obstacle_residual(X, sph[:, :3], sph[:, 3], cfg)
+    vec_close(h.unlane(Cm, (B, N * 16)), Cref, t["vec_rel"], "obstacle residual")
+    vec_close(h.to_host(cmin), Cref.min(1), t["vec_rel"], "obstacle min")
+    vec_close(h.to_host(viol), np.maximum(0, -Cref).sum(1), t["vec_rel"] * 4, "obstacle violation")
+    C0, cmin0, viol0 = h.ops.obstacle_residual(prm, h.lane(X, B), h.prob(np.zeros((0, 4))))
+    assert tuple(C0.shape) == (0, B) and np.all(np.isinf(h.to_host(cmin0))) and np.all(h.to_host(viol0) == 0)
+    # a10
+    Cp = h.ops.physical_constraints(prm, h.lane(X, B))
+    vec_close(h.unlane(Cp, (B, 4 * N)), orc.physical_constraints(X, cfg), t["vec_rel"], "physical constraints")
+    # a11 / a12 incl. degenerate thrust rows
+    Te = T.copy()
+    if N >= 6:
+        Te[0, 1] = 0.0; Te[0, 3] = [7.0, 0, 0]; Te[1, 0] = 0.0; Te[1, 2] = [-3.0, 0, 0]; Te[2, 4] = [0, 5.0, 0]
+        Te[3, 2] = [1e-7, 0, 0]
+    acc, att, rates, thr = h.ops.extract(prm, h.lane(Te, B))
+    Xe = X.copy(); Xe[:, 6 * N:] = Te.reshape(B, -1)
+    ex = orc.extract_solution_batch(Xe, cfg)
+    vec_close(h.unlane(acc, (B, N, 3)), ex["accelerations"], t["vec_rel"], "accelerations")
+    assert np.max(np.abs(h.unlane(att, (B, N, 3)) - ex["attitudes"])) <= t["pos"], "attitudes"
+    assert np.max(np.abs(h.unlane(rates, (B, N, 3)) - ex["body_rates"])) <= t["rates"], "body rates"
+    vec_close(h.unlane(thr, (B, N)), ex["thrusts"], t["vec_rel"], "thrusts")
+    # shooting form, every requested variant, with the fused argmin key
+    c_ref, g_ref = orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+    P_ref, V_ref = orc.rollout(p0, v0, T, cfg)
+    for var in variants:
+        h.ops.lib.set_rollout_variant(var)
+        try:
+            key = h.to_dev(np.array([-1], dtype=np.int64))
+            cost, gT, P, V = h.ops.rollout_cost_grad(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
+                                                     want_states=True, key=key, index_base=7000)
+            ch = h.to_host(cost).astype(float)
+            assert np.max(np.abs(ch - c_ref) / np.abs(c_ref)) <= t["cost_rel"], f"rollout cost (variant {var})"
+            vec_close(h.unlane(gT, (B, N, 3)), g_ref, t["vec_rel"], f"rollout gradient (variant {var})")
+            assert np.max(np.abs(h.unlane(P, (B, N, 3)) - P_ref)) <= t["pos"], f"rollout positions (variant {var})"
+            assert np.max(np.abs(h.unlane(V, (B, N, 3)) - V_ref)) <= t["pos"], f"rollout velocities (variant {var})"
+            idx, kc = h.ops.decode_key(key)
+            assert idx == 7000 + int(np.argmin(h.to_host(cost))), f"fused argmin (variant {var})"
+            assert kc == np.float32(h.to_host(cost).min())
+            c_only, g_none, _, _ = h.ops.rollout_cost_grad(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
+                                                           want_grad=False)
+            assert g_none is None and np.array_equal(h.to_host(c_only), h.to_host(cost))
+        finally:
+            h.ops.lib.set_rollout_variant(0)
+    # the rolled-out states satisfy the reference's dynamics constraints (a8 == 0)
+    Xr = orc.pack(P_ref, V_ref, T)
+    Rr = h.ops.dynamics_residual(prm, h.lane(Xr, B), h.lane(p0, B), h.lane(v0, B))
+    assert np.max(np.abs(h.to_host(Rr))) <= (1e-4 if h.dt == np.float32 else 1e-12)
+    # a16
+    Pv = rng.uniform(0.2, 5, (B, N, 3)); Vv = rng.uniform(-19, 19, (B, N, 3))
+    Pv[1, 0, 2] = 0.05; Vv[2, N - 1, 1] = -20.5
+    if B > 4:
+        Pv[3, N // 2, 0] = np.nan; Pv[4, 0, 1] = np.inf
+    valid = h.to_host(h.ops.is_plan_valid(prm, h.lane(Pv, B), h.lane(Vv, B)))
+    expect = np.array([orc.is_plan_valid(Pv[i], Vv[i]) for i in range(B)], dtype=np.int32)
+    assert np.array_equal(valid, expect), "is_plan_valid"
+    # standalone argmin + transpose
+    key = h.ops.argmin(f, index_base=5)
+    assert h.ops.decode_key(key)[0] == 5 + int(np.argmin(h.to_host(f)))
+    Xt = h.ops.transpose(h.prob(X))
+    assert np.array_equal(h.to_host(Xt), X.astype(h.dt).T)
+
+
+# --------------------------------------------------------------------------------------- solver
+def solve_params(c) -> Params:
+    return Params.reference_defaults(horizon=c["N"], dt=c["dt"], max_iterations=c["maxiter"], pgtol=c["tol"],
+                                     ftol=10 * c["tol"])
+
+
+def check_solver_golden(h: Harness, data, meta, keys=None):
+    """The batched solve against what the reference itself returned (tests/golden/solve_cases)."""
+    t = h.tol
+    worst = 0.0
+    for c in meta["cases"]:
+        k = c["key"]
+        if keys is not None and k not in keys:
+            continue
+        prm = solve_params(c)
+        N = c["N"]
+        out = h.ops.solve(prm, h.prob(data[k + "p0"][None]), h.prob(data[k + "v0"][None]), h.prob(data[k + "goal"][None]))
+        info = h.ops.info_to_host(out["info"])[0]
+        assert (int(info["nit"]), int(info["nfev"]), int(info["status"])) == (c["nit"], c["nfev"], c["status"]), (k, info)
+        x = h.to_host(out["x"])[0].astype(float)
+        assert np.max(np.abs(x - data[k + "x"])) <= t["pos"], (k, "x")
+        worst = max(worst, float(np.max(np.abs(x[:3 * N] - data[k + "positions"].ravel()))))
+        assert abs(float(info["fun"]) - float(data[k + "fun"])) <= 1e-5 * abs(float(data[k + "fun"])), (k, "fun")
+        for name in ("accelerations", "attitudes", "thrusts"):
+            assert np.max(np.abs(h.to_host(out[name])[0] - data[k + name])) <= t["pos"], (k, name)
+        assert np.max(np.abs(h.to_host(out["body_rates"])[0] - data[k + "body_rates"])) <= t["rates"], (k, "body_rates")
+    return worst
+
+
+def check_solver_extraction(h: Harness, N: int, B: int, seed: int = 3):
+    """pgtol = inf makes L-BFGS-B return the projected x0 untouched, which isolates the solver's
+    own cold-start / projection / extraction code on arbitrary thrust sequences."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N, pgtol=1e300)
+    cfg = oracle_cfg(Params.reference_defaults(horizon=N))
+    p0, v0, goal, T = random_batch(rng, B, N, spread=6.0)
+    if N >= 6:
+        T[0, 1] = 0.0; T[0, 3] = [7.0, 0, 0]; T[1, 0] = 0.0; T[1, 2] = [-3.0, 0, 0]; T[2, 4] = [0, 5.0, 0]
+    X0 = np.concatenate([rng.uniform(-120, 120, (B, 3 * N)), rng.uniform(-15, 15, (B, 3 * N)), T.reshape(B, -1)], axis=1)
+    out = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal), x0=h.prob(X0))
+    b = orc.bounds(cfg)
+    Xc = np.clip(X0.astype(h.dt).astype(float), b[:, 0], b[:, 1])
+    info = h.ops.info_to_host(out["info"])
+    assert np.all(info["nit"] == 0) and np.all(info["nfev"] == 1) and np.all(info["task"] == 1)
+    vec_close(h.to_host(out["x"]).astype(float), Xc, h.tol["vec_rel"], "projected x0")
+    ex = orc.extract_solution_batch(Xc, cfg)
+    t = h.tol
+    vec_close(h.to_host(out["accelerations"]), ex["accelerations"], t["vec_rel"], "accelerations")
+    assert np.max(np.abs(h.to_host(out["attitudes"]) - ex["attitudes"])) <= t["pos"]
+    assert np.max(np.abs(h.to_host(out["body_rates"]) - ex["body_rates"])) <= t["rates"]
+    vec_close(h.to_host(out["thrusts"]), ex["thrusts"], t["vec_rel"], "thrusts")
+    # cold start of the solver == a3 projected into the box (x0 = None path)
+    out2 = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
+    ref0 = orc.straight_line_init(p0.astype(h.dt).astype(float), v0.astype(h.dt).astype(float),
+                                  goal.astype(h.dt).astype(float), cfg)
+    vec_close(h.to_host(out2["x"]).astype(float), np.clip(ref0, b[:, 0], b[:, 1]), 10 * h.tol["vec_rel"], "cold start")
+
+
+def check_solver_vs_oracle(h: Harness, N: int, B: int, seed: int = 11, **overrides):
+    """Random problems of the cfg-2 distribution: batched HIP solve vs the oracle (SciPy) one by one.
+    Returns (max position error, fraction of problems whose nit/nfev/status differ)."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N, **overrides)
+    cfg = oracle_cfg(prm)
+    p0, v0, goal, _ = random_batch(rng, B, N)
+    out = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
+    info = h.ops.info_to_host(out["info"])
+    X = h.to_host(out["x"]).astype(float)
+    worst, mism = 0.0, 0
+    for i in range(B):
+        xr, ir = orc.solve(p0[i].astype(h.dt).astype(float), v0[i].astype(h.dt).astype(float),
+                           goal[i].astype(h.dt).astype(float), cfg)
+        same = (int(info["nit"][i]), int(info["nfev"][i]), int(info["status"][i])) == (ir["nit"], ir["nfev"], ir["status"])
+        mism += 0 if same else 1
+        if same:
+            worst = max(worst, float(np.max(np.abs(X[i, :3 * N] - xr[:3 * N]))))
+    return worst, mism / B

@@ -1,0 +1,88 @@
+"""CPU suite: the UNMODIFIED product kernels (dart_planner_amd/csrc/*.hip) compiled for the host by
+tests/emu (one std::thread per lane) and driven through the same C ABI and the same Ops front-end
+as on the GPU, checked against the oracle and the reference's golden vectors.  This is test
+infrastructure to debug kernel arithmetic and host logic without a GPU; the product never loads
+tests/emu/libse3mpc_emu.so, and the `-m gpu` suite repeats every check on the real library."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+import build_emu  # noqa: E402
+from numpy_backend import NumpyBackend  # noqa: E402
+
+from dart_planner_amd import capi  # noqa: E402
+from dart_planner_amd.ops import Ops  # noqa: E402
+import parity_checks as pc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def emu_ops():
+    lib = capi.Library(build_emu.build())
+    return Ops(NumpyBackend(), lib)
+
+
+def harness(ops, dt):
+    return pc.Harness(ops, lambda a: a, lambda a: a, dt)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (30, 66), (7, 9)])
+def test_lane_kernels(emu_ops, dt, N, B):
+    # B = 70 / 66 leave a partial last wavefront (tail lanes); N = 7 takes the generic (non-template) path
+    pc.check_lane_kernels(harness(emu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5))
+
+
+def test_lane_kernels_other_dt(emu_ops):
+    pc.check_lane_kernels(harness(emu_ops, np.float64), 20, 8, seed=2, dt=0.05)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_reproduces_reference_solves(emu_ops, golden_solve, dt):
+    data, meta = golden_solve
+    # contract case, a 3-iteration case, N = 1, N = 2, the box-clipped start and one ABNORMAL line search
+    worst = pc.check_solver_golden(harness(emu_ops, dt), data, meta, keys={"s00_", "s01_", "s26_", "s31_", "s32_", "s33_"})
+    assert worst <= (1e-4 if dt == np.float32 else 1e-9)
+
+
+def test_solver_extraction_and_cold_start(emu_ops):
+    pc.check_solver_extraction(harness(emu_ops, np.float64), 6, 4)
+    pc.check_solver_extraction(harness(emu_ops, np.float32), 20, 3)
+
+
+def test_empty_batch_and_error_codes(emu_ops):
+    lib, be = emu_ops.lib, emu_ops.be
+    prm = capi.Params.reference_defaults(horizon=6)
+    z = np.zeros((3, 0), dtype=np.float32)
+    assert emu_ops.init(prm, z, z, z).shape == (54, 0)                       # B == 0 is a no-op
+    out = emu_ops.solve(prm, np.zeros((0, 3)), np.zeros((0, 3)), np.zeros((0, 3)))
+    assert out["x"].shape == (0, 54)
+    a = np.zeros((3, 4), dtype=np.float32); X = np.zeros((54, 4), dtype=np.float32); f = np.zeros(4, dtype=np.float32)
+    st = lambda *args, **kw: lib.call_status(*args, **kw)
+    assert st("cost_grad", "f32", 4, 4, 0, be.ptr(a), be.ptr(f), 0, 0, params=prm) == -1          # NULL X
+    assert st("cost_grad", "f32", 4, 4, be.ptr(X), 0, be.ptr(f), 0, 0, params=prm) == -1          # NULL goal with has_goal
+    assert st("cost_grad", "f32", 4, 4, be.ptr(X), 0, be.ptr(f), 0, 0, params=prm.copy(has_goal=0)) == 0
+    assert st("cost_grad", "f32", 5, 4, be.ptr(X), be.ptr(a), be.ptr(f), 0, 0, params=prm) == -3  # ld < B
+    assert st("cost_grad", "f32", -1, 4, be.ptr(X), be.ptr(a), be.ptr(f), 0, 0, params=prm) == -3
+    for bad, code in ((dict(horizon=0), -2), (dict(horizon=65), -2), (dict(dt=0.0), -4), (dict(mass=float("nan")), -4),
+                      (dict(max_corrections=11), -4), (dict(max_thrust=1.0), -4)):
+        assert lib.check_params(prm.copy(**bad)) == code, bad
+        assert st("cost_grad", "f32", 4, 4, be.ptr(X), be.ptr(a), be.ptr(f), 0, 0, params=prm.copy(**bad)) == code
+    assert st("obstacle_residual", "f32", 4, 4, be.ptr(X), 0, 257, 0, 0, 0, 0, params=prm) == -3  # K > SE3MPC_MAX_SPHERES
+    assert st("rollout_cost_grad", "f32", 4, 4, be.ptr(a), be.ptr(a), be.ptr(a), be.ptr(X), be.ptr(f), 0, be.ptr(X), 0,
+              0, 0, 0, params=prm) == -1                                                          # P without V
+    with pytest.raises(capi.Se3mpcError):
+        lib.call("cost_grad", "f32", 4, 4, 0, be.ptr(a), be.ptr(f), 0, 0, params=prm)
+
+
+def test_defaults_and_key_codec(emu_ops):
+    lib = emu_ops.lib
+    assert lib.default_params().as_dict() == capi.Params.reference_defaults().as_dict()
+    assert lib.abi_version() == 1
+    for c in (0.0, 1.5, 3.0e6, -2.0, float("inf")):
+        bits = np.float32(c).view(np.uint32)
+        ob = (~bits) & 0xFFFFFFFF if bits & 0x80000000 else bits | 0x80000000
+        key = (int(ob) << 32) | 1234
+        assert lib.key_index(key) == 1234 and lib.key_cost(key) == np.float32(c)

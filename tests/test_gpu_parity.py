@@ -1,0 +1,163 @@
+"""GPU suite (`-m gpu`): the HIP kernels of libse3mpc.so on a real MI355X, called through the C ABI
+(ctypes) with PyTorch-ROCm tensors, against the oracle and the reference's golden vectors, plus
+size-independent properties at BASELINE.json's full sizes."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import parity_checks as pc  # noqa: E402
+from oracle import se3mpc_oracle as orc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu_ops():
+    import torch
+    assert torch.cuda.is_available(), "the gpu suite needs an MI355X"
+    from dart_planner_amd.ops import Ops, TorchBackend
+    ops = Ops(TorchBackend("cuda:0"))
+    assert ops.lib.device_count() >= 1, "no gfx950 device visible to libse3mpc"
+    assert os.path.basename(ops.lib.path) == "libse3mpc.so"
+    return ops
+
+
+def harness(ops, dt):
+    import torch
+    return pc.Harness(ops, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0"),
+                      lambda a: a.detach().cpu().numpy(), dt)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (20, 257), (30, 1000), (50, 129), (64, 65), (7, 9), (33, 200)])
+def test_lane_kernels(gpu_ops, dt, N, B):
+    pc.check_lane_kernels(harness(gpu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5))
+
+
+def test_lane_kernels_other_dt(gpu_ops):
+    pc.check_lane_kernels(harness(gpu_ops, np.float64), 20, 300, seed=2, dt=0.05)
+    pc.check_lane_kernels(harness(gpu_ops, np.float32), 20, 300, seed=2, dt=0.1)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_reproduces_every_reference_solve(gpu_ops, golden_solve, dt):
+    data, meta = golden_solve
+    worst = pc.check_solver_golden(harness(gpu_ops, dt), data, meta)
+    print(f"worst position error vs the reference ({np.dtype(dt).name}): {worst:.3e} m")
+    assert worst <= (1e-4 if dt == np.float32 else 1e-9)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N", [6, 20, 30, 50, 64])
+def test_solver_extraction_and_cold_start(gpu_ops, dt, N):
+    pc.check_solver_extraction(harness(gpu_ops, dt), N, 37)
+
+
+@pytest.mark.parametrize("N,B", [(6, 256), (20, 128), (30, 256), (50, 96)])
+def test_batched_solve_matches_scipy_problem_by_problem(gpu_ops, N, B):
+    """Config 1/2 of BASELINE.json: random (state, goal) pairs, reference options."""
+    for dt, tol in ((np.float64, 1e-9), (np.float32, 1e-4)):
+        worst, mismatch = pc.check_solver_vs_oracle(harness(gpu_ops, dt), N, B, seed=N)
+        print(f"N={N} B={B} {np.dtype(dt).name}: max position error {worst:.3e} m, iteration-count mismatches {mismatch:.4f}")
+        assert worst <= tol
+        assert mismatch <= (0.0 if dt == np.float64 else 0.02)
+
+
+def test_batched_solve_tight_tolerances(gpu_ops):
+    """Many L-BFGS-B iterations per problem (memory fills up, line searches fail on the reference's
+    inconsistent gradient): f64 must follow SciPy exactly."""
+    worst, mismatch = pc.check_solver_vs_oracle(harness(gpu_ops, np.float64), 20, 48, seed=5, pgtol=1e-9, ftol=1e-8,
+                                                max_iterations=40)
+    assert mismatch == 0.0 and worst <= 1e-8
+
+
+# ------------------------------------------------------------------ full sizes: properties
+def test_full_size_rollout_properties(gpu_ops):
+    """B = 65536, N = 30 (config 4's per-node batch) and B = 8192, N = 50 with K = 16 spheres (config 3):
+    too big for the per-problem oracle, so check invariants: (1) the rolled-out states zero the
+    reference's dynamics residual; (2) cost(rollout) == objective(packed rollout); (3) the adjoint
+    gradient satisfies the directional-derivative identity of a quadratic; (4) fused key == argmin;
+    (5) obstacle min/violation reductions agree with the materialised residuals."""
+    import torch
+    from dart_planner_amd.capi import Params
+    ops = gpu_ops
+    dev = ops.be.device
+    for N, B in ((30, 65536), (50, 8192)):
+        prm = Params.reference_defaults(horizon=N)
+        g = torch.Generator(device=dev); g.manual_seed(N)
+        p0 = torch.rand(3, B, device=dev, generator=g) * 40 - 20
+        v0 = torch.rand(3, B, device=dev, generator=g) * 10 - 5
+        goal = torch.rand(3, B, device=dev, generator=g) * 40 - 20
+        T = torch.randn(3 * N, B, device=dev, generator=g) * 2
+        T[2::3] += 14.715
+        key = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        cost, gT, P, V = ops.rollout_cost_grad(prm, p0, v0, goal, T, want_states=True, key=key)
+        X = torch.cat([P, V, T], dim=0).contiguous()
+        R = ops.dynamics_residual(prm, X, p0, v0)
+        assert float(R.abs().max()) <= 2e-4                                        # (1) f32 roundoff of |P| ~ 1e2
+        f, _ = ops.cost_grad(prm, X, goal, want_grad=False)
+        assert float(((f - cost).abs() / cost).max()) <= 2e-6                       # (2)
+        dT = torch.randn(3 * N, B, device=dev, generator=g)
+        cp, _, _, _ = ops.rollout_cost_grad(prm, p0, v0, goal, T + dT, want_grad=False)
+        cm, _, _, _ = ops.rollout_cost_grad(prm, p0, v0, goal, T - dT, want_grad=False)
+        dd = (gT * dT).sum(0)                                                       # (3) exact for a quadratic
+        fd = (cp.double() - cm.double()) / 2
+        assert float(((dd.double() - fd).abs() / (fd.abs() + 1e-3 * cost.double())).max()) <= 2e-4
+        idx, kc = ops.decode_key(key)
+        assert idx == int(torch.argmin(cost)) and kc == float(cost.min())           # (4)
+        sph = torch.cat([torch.round(torch.rand(16, 3, device=dev, generator=g) * 30) / 2, torch.ones(16, 1, device=dev)], 1)
+        Cm, cmin, viol = ops.obstacle_residual(prm, X, sph)
+        assert torch.equal(Cm.min(0).values, cmin)                                  # (5)
+        assert float((viol - torch.clamp(-Cm, min=0).sum(0)).abs().max()) <= 1e-3 * max(1.0, float(viol.max()))
+
+
+def test_monte_carlo_restarts_f64_vs_f32(gpu_ops):
+    """Config 5 shape (initial states x restarts), reduced to 256 x 32 for test time: restart 0 is the
+    reference cold start, the others perturb the thrust block; the f32 solve tracks the f64 solve
+    and restart 0 equals the plain cold-start solve."""
+    import torch
+    from dart_planner_amd.capi import Params
+    ops = gpu_ops
+    dev = ops.be.device
+    N, S, Rr = 20, 256, 32
+    prm = Params.reference_defaults(horizon=N)
+    cfg = orc.OracleConfig(prediction_horizon=N)
+    rng = np.random.default_rng(9)
+    p0, v0, goal, _ = pc.random_batch(rng, S, N)
+    x0 = orc.straight_line_init(p0, v0, goal, cfg)                                   # (S, 9N)
+    X0 = np.repeat(x0[:, None, :], Rr, axis=1)
+    X0[:, 1:, 6 * N:] += rng.normal(0, 1.0, (S, Rr - 1, 3 * N))
+    rep = lambda a: np.repeat(a[:, None, :], Rr, axis=1).reshape(S * Rr, 3)
+    outs = {}
+    for dt in (np.float64, np.float32):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(dev)
+        o = ops.solve(prm, t(rep(p0)), t(rep(v0)), t(rep(goal)), x0=t(X0.reshape(S * Rr, 9 * N)), want_trajectory=False)
+        outs[dt] = (o["x"].cpu().numpy().astype(float), ops.info_to_host(o["info"]))
+    x64, i64 = outs[np.float64]; x32, i32 = outs[np.float32]
+    same = (i64["nit"] == i32["nit"]) & (i64["nfev"] == i32["nfev"])
+    assert same.mean() >= 0.98
+    assert np.max(np.abs(x64[same][:, :3 * N] - x32[same][:, :3 * N])) <= 1e-4
+    t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cold = ops.solve(prm, t64(p0), t64(v0), t64(goal), want_trajectory=False)["x"].cpu().numpy()
+    assert np.max(np.abs(cold - x64.reshape(S, Rr, -1)[:, 0])) <= 1e-9
+
+
+def test_wave_ops_selftest(gpu_ops):
+    """The DPP reductions behind every dot product of the solver, on known data."""
+    import torch
+    ops = gpu_ops
+    dev = ops.be.device
+    # cost = lane index pattern: the fused key must find the minimum wherever it sits in the wavefront
+    from dart_planner_amd.capi import Params
+    prm = Params.reference_defaults(horizon=6)
+    for pos in (0, 1, 15, 16, 31, 32, 47, 48, 62, 63):
+        B = 64
+        p0 = torch.zeros(3, B, device=dev); v0 = torch.zeros(3, B, device=dev)
+        goal = torch.full((3, B), 50.0, device=dev)
+        goal[:, pos] = 0.0                                    # trajectory `pos` is already at its goal: smallest cost
+        T = torch.zeros(18, B, device=dev); T[2::3] = 14.715
+        key = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        cost, *_ = ops.rollout_cost_grad(prm, p0, v0, goal, T, want_grad=False, key=key)
+        assert ops.decode_key(key)[0] == pos == int(torch.argmin(cost))
