@@ -257,7 +257,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   double* wbp = vv + 2 * m;                            // [2m]  row of W at a breakpoint
   double* wv = wbp + 2 * m;                            // [2m]  subspace rhs
   double* sc = wv + 2 * m;                             // [8]   scalars handed out of scalar sections
-  IO* ws = reinterpret_cast<IO*>(sc + 8);              // [m][npad]
+  double* xlast = sc + 8;                              // [npad] the x of the last counted evaluation
+  IO* ws = reinterpret_cast<IO*>(xlast + npad);        // [m][npad]
   IO* wy = ws + m * npad;                              // [m][npad]
   double* scratch = reinterpret_cast<double*>(ws);     // reused after the solve (needs 12*64 doubles <= 2*m*npad*sizeof(IO))
 
@@ -304,7 +305,18 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   }
 
   // objective (planner.py:516-550) and the reference's gradient (planner.py:552-580) at x
+  // nfev counts like scipy's ScalarFunction: asking again for the x evaluated last (a line search
+  // whose steps shrank below rounding) returns the same (f, g) and is not counted.
+  int nfev = 0;
   auto eval_fg = [&]() -> double {
+    bool moved = false;
+#pragma unroll
+    for (int j = 0; j < J; ++j) moved = moved || !(x[j] == xlast[lane + kWave * j]);
+    if (wave_ballot(moved) != 0ull) {
+      ++nfev;
+#pragma unroll
+      for (int j = 0; j < J; ++j) xlast[lane + kWave * j] = x[j];
+    }
     double part = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
@@ -350,13 +362,14 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   auto WY = [&](int c, int j) -> IO& { return wy[c * npad + lane + kWave * j]; };
 
   // ---- L-BFGS-B state (identical in every lane)
-  int col = 0, iupdat = 0, iter = 0, nit = 0, nfev = 0;
+  int col = 0, iupdat = 0, iter = 0, nit = 0;
   double theta = 1.0;
   int iwhere[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) iwhere[j] = ((code[j] & 3) == 3) ? 3 : 0;   // padding = fixed variables
+#pragma unroll
+  for (int j = 0; j < J; ++j) xlast[lane + kWave * j] = __builtin_nan("");
   double f = eval_fg();
-  nfev = 1;
   double sbgnrm = projgr();
   int status = 0, task = 0;
   double fold = f;
@@ -686,7 +699,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       start = false;
       if (lt == LS_CONV || lt == LS_WARN) break;
       if (lt == LS_ERROR) { ls_info = -4; break; }          // dcsrch rejected its inputs (never with a feasible d)
-      ++ifun; ++nfev; iback = ifun - 1;
+      ++ifun; iback = ifun - 1;
       if (iback >= q.maxls) break;
       if (stp == 1.0) {
 #pragma unroll
@@ -702,7 +715,6 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
       for (int j = 0; j < J; ++j) { x[j] = xo[j]; g[j] = go[j]; }
       f = fold;
-      if (ls_info == 0) --nfev;
       if (col == 0) { task = SE3MPC_TASK_ABNORMAL; status = 2; break; }
       col = 0; theta = 1.0; iupdat = 0;
       continue;
@@ -845,7 +857,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 }
 
 static size_t solve_lds_bytes(int m, int J, size_t io_size) {
-  const size_t doubles = (size_t)3 * m * m + 4 * m * m + 5 * 2 * m + 8;
+  const size_t doubles = (size_t)3 * m * m + 4 * m * m + 5 * 2 * m + 8 + (size_t)kWave * J;
   size_t pairs = (size_t)2 * m * kWave * J * io_size;
   const size_t scratch = (size_t)12 * kWave * sizeof(double);
   if (pairs < scratch) pairs = scratch;

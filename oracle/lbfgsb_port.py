@@ -580,11 +580,24 @@ def minimize(fun_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]], x0,
              pgtol=0.05, maxiter=15, maxfun=15000, maxls=20, trace=False) -> Result:
     """scipy.optimize._lbfgsb_py._minimize_lbfgsb + mainlb, for an all-boxed problem."""
     n = len(x0)
+    # SciPy evaluates through ScalarFunction, which returns its cached (f, g) -- and does not count an
+    # evaluation -- when asked for the x it evaluated last (a line search whose steps have shrunk
+    # below rounding asks for the same point again).  result.nfev is that count.
+    raw_fg = fun_and_grad
+    cache = {"x": None, "f": None, "g": None, "n": 0}
+
+    def fun_and_grad(xq):
+        if cache["x"] is None or not np.array_equal(xq, cache["x"]):
+            cache["x"] = np.array(xq, float)
+            cache["f"], cache["g"] = raw_fg(cache["x"])
+            cache["n"] += 1
+        return cache["f"], cache["g"]
+
     S = Lbfgsb(n, m, lo, hi, ftol, pgtol, maxls)
     x = np.clip(np.asarray(x0, float), lo, hi)          # active(): project x0 into the box
     S.iwhere[:] = np.where(S.u - S.l <= 0.0, 3, 0)
     f, g = fun_and_grad(x); g = np.asarray(g, float).copy()
-    nfev, nit = 1, 0
+    nfev, nit = cache["n"], 0
     tr: List[np.ndarray] = []
     sbgnrm = S.projgr(x, g)
     if sbgnrm <= pgtol:
@@ -648,22 +661,17 @@ def minimize(fun_and_grad: Callable[[np.ndarray], Tuple[float, np.ndarray]], x0,
             if ls_task.startswith("ERROR"):
                 # dcsrch rejected its inputs: lnsrlb keeps going as if FG were requested (task != CONV/WARN)
                 pass
-            ifun += 1; nfev += 1; iback = ifun - 1
+            ifun += 1; iback = ifun - 1
             if iback >= maxls:
                 break
             x = z.copy() if stp == 1.0 else stp * d + t_x
             f, g = fun_and_grad(x); g = np.asarray(g, float).copy()
+            nfev = cache["n"]
         if ls_info != 0 or iback >= maxls:
             # restore the previous iterate
             x, g, f = t_x, r_g, fold
             if S.col == 0:
-                # abnormal termination
-                if ls_info == 0:
-                    nfev -= 1
-                it += 0
                 return Result(x, f, nit, nfev, 2, "ABNORMAL_TERMINATION_IN_LNSRCH", tr)
-            if ls_info == 0:
-                nfev -= 1
             S.reset_memory()
             continue
         # ---------------- new iterate

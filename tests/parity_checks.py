@@ -131,7 +131,8 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
             assert kc == np.float32(h.to_host(cost).min())
             c_only, g_none, _, _ = h.ops.rollout_cost_grad(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
                                                            want_grad=False)
-            assert g_none is None and np.array_equal(h.to_host(c_only), h.to_host(cost))
+            # (another template instantiation: same arithmetic, FMA contraction may differ in the last bit)
+            assert g_none is None and np.allclose(h.to_host(c_only), h.to_host(cost), rtol=t["cost_rel"], atol=0)
         finally:
             h.ops.lib.set_rollout_variant(0)
     # the rolled-out states satisfy the reference's dynamics constraints (a8 == 0)
