@@ -1,0 +1,1 @@
+"""Import-name shim package."""

@@ -1,0 +1,307 @@
+"""SE3MPCPlanner -- host-side mirror of the reference planner, backed by the HIP solver.
+
+Same class / method names, arguments and error behaviour as
+``src/dart_planner/planning/se3_mpc_planner.py`` of DART-Planner ("planner.py" below), so the
+Planner->Controller contract (tests/test_planner_controller_contract.py of the reference) holds
+unchanged: ``plan_trajectory(state, goal) -> Trajectory``.  Everything the reference computes with
+NumPy loops + ``scipy.optimize.minimize(method="L-BFGS-B")`` between ``sense`` and ``act`` --
+cold start, box, objective/gradient, the L-BFGS-B iterations, accelerations / attitudes / body
+rates / thrust magnitudes -- runs in ONE launch of ``se3mpc_solve_*`` (dart_planner_amd/csrc/
+solve_kernel.hip) on the MI355X.  There is no CPU fallback: without a HIP device or the built
+library the first plan raises.
+
+Beyond the reference (its own construct): ``plan_batch`` solves B
+independent (state, goal) problems in one launch and ``plan_with_restarts`` runs R perturbed cold
+starts of one problem and returns the best -- restart 0 is always the reference's cold start.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import time
+from dataclasses import dataclass, fields
+from typing import Any, Dict, List, Optional, Tuple
+
+import numpy as np
+
+from ..capi import Params, TASK_MESSAGES
+from ..common.types import DroneState, Trajectory
+from ..common.units import ensure_units, to_float
+from .base_planner import BasePlanner, PlannerFactory
+
+_log = logging.getLogger(__name__)
+
+
+@dataclass(frozen=True)
+class SE3MPCConfig:
+    """planner.py:36-79 -- same fields and defaults; limits are SI magnitudes (a pint Quantity is
+    accepted and converted)."""
+    prediction_horizon: int = 6
+    dt: float = 0.125                       # overridden by the timing manager (planner.py:99-105)
+    max_velocity: float = 10.0              # m/s
+    max_acceleration: float = 15.0          # m/s^2
+    max_jerk: float = 20.0                  # m/s^3   (never read by the solver, as in the reference)
+    max_thrust: float = 25.0                # N
+    min_thrust: float = 2.0                 # N
+    max_tilt_angle: float = math.pi / 4     # rad
+    max_angular_velocity: float = 4.0       # rad/s   (never read)
+    position_weight: float = 100.0
+    velocity_weight: float = 10.0
+    acceleration_weight: float = 1.0
+    thrust_weight: float = 0.1
+    angular_weight: float = 10.0            # never read
+    obstacle_weight: float = 1000.0         # never read (planner.py:63)
+    safety_margin: float = 1.5              # m
+    max_iterations: int = 15
+    convergence_tolerance: float = 5e-2
+
+    def __post_init__(self):
+        for name, unit in (("max_velocity", "m/s"), ("max_acceleration", "m/s^2"), ("max_jerk", "m/s^3"),
+                           ("max_thrust", "N"), ("min_thrust", "N"), ("max_tilt_angle", "rad"),
+                           ("max_angular_velocity", "rad/s"), ("safety_margin", "m")):
+            object.__setattr__(self, name, float(ensure_units(getattr(self, name), unit, f"SE3MPCConfig.{name}")))
+
+
+class SE3MPCPlanner(BasePlanner):
+    """planner.py:82-757."""
+
+    def __init__(self, config: Optional[SE3MPCConfig] = None, *, precision: str = "f64", device=None) -> None:
+        if config is None:
+            config = SE3MPCConfig()
+        elif isinstance(config, dict):      # PlannerFactory.create hands over a dict (base_planner.py:131)
+            known = {f.name for f in fields(SE3MPCConfig)}
+            config = SE3MPCConfig(**{k: v for k, v in config.items() if k in known})
+        from ..common.timing_alignment import get_timing_manager
+        aligned_dt = get_timing_manager().get_planner_dt()                      # planner.py:99-105
+        config = SE3MPCConfig(**{**{f.name: getattr(config, f.name) for f in fields(SE3MPCConfig)}, "dt": aligned_dt})
+        super().__init__({f.name: getattr(config, f.name) for f in fields(SE3MPCConfig)})   # planner.py:124-145
+        self.se3_config = config
+        self.mass = 1.5                                                          # planner.py:149-151
+        self.gravity = 9.81
+        self.hover_thrust = self.mass * self.gravity
+        self.goal_position: Optional[np.ndarray] = None
+        self.obstacles: List[Tuple[np.ndarray, float]] = []
+        self.last_solution: Optional[Dict[str, np.ndarray]] = None               # never assigned, as in the reference
+        self.warm_start_enabled = True
+        self.planning_times: List[float] = []
+        self.plan_count = 0
+        self.convergence_history: List[bool] = []
+        self.last_result: Dict[str, Any] = {}
+        if precision not in ("f32", "f64"):
+            raise ValueError("precision must be 'f32' or 'f64'")
+        self.precision = precision
+        self._device = device
+        self._ops = None
+        self._io = {}
+        self.logger = _log
+
+    # ------------------------------------------------------------------ device plumbing
+    def _get_ops(self):
+        if self._ops is None:
+            from ..ops import Ops, TorchBackend
+            self._ops = Ops(TorchBackend(self._device))      # raises without a HIP device / built library
+        return self._ops
+
+    def _params(self, **overrides) -> Params:
+        c = self.se3_config
+        p = Params.reference_defaults(
+            horizon=c.prediction_horizon, dt=c.dt, mass=self.mass, gravity=self.gravity,
+            position_weight=c.position_weight, velocity_weight=c.velocity_weight,
+            acceleration_weight=c.acceleration_weight, thrust_weight=c.thrust_weight,
+            max_velocity=c.max_velocity, max_acceleration=c.max_acceleration, max_thrust=c.max_thrust,
+            min_thrust=c.min_thrust, max_tilt_angle=c.max_tilt_angle, safety_margin=c.safety_margin,
+            max_iterations=c.max_iterations, pgtol=c.convergence_tolerance, ftol=10 * c.convergence_tolerance,
+            has_goal=int(self.goal_position is not None))
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        return p
+
+    # ------------------------------------------------------------------ planner.py:175-228
+    def set_goal(self, goal_position) -> None:
+        self.goal_position = np.array(ensure_units(goal_position, "m", "SE3MPCPlanner.set_goal"), dtype=float)
+        self.logger.debug("SE(3) MPC goal set to: %s", self.goal_position)
+
+    def add_obstacle(self, center, radius) -> None:
+        c = np.array(ensure_units(center, "m", "SE3MPCPlanner.add_obstacle center"), dtype=float)
+        r = float(ensure_units(radius, "m", "SE3MPCPlanner.add_obstacle radius"))
+        self.obstacles.append((c, r))
+
+    def clear_obstacles(self) -> None:
+        self.obstacles.clear()
+
+    def sense(self, current_state: DroneState, goal_position):
+        goal_position = ensure_units(goal_position, "m", "SE3MPCPlanner.sense goal_position")
+        if self.goal_position is None or np.linalg.norm(to_float(self.goal_position - goal_position)) > 0.5:
+            self.set_goal(goal_position)                                        # planner.py:197-201
+        return current_state, self.goal_position, list(self.obstacles)
+
+    def plan(self, current_state: DroneState) -> Dict[str, np.ndarray]:
+        return self._solve_se3_mpc(current_state)
+
+    def act(self, solution: Dict[str, np.ndarray], current_state: DroneState, start_time: float) -> Trajectory:
+        return self._create_trajectory_from_solution(solution, start_time)
+
+    def plan_trajectory(self, current_state: DroneState, goal_position) -> Trajectory:
+        t0 = time.perf_counter()
+        current_state, _, _ = self.sense(current_state, goal_position)
+        solution = self.plan(current_state)
+        trajectory = self.act(solution, current_state, time.time())
+        ms = (time.perf_counter() - t0) * 1e3
+        self.planning_times.append(ms)
+        self.plan_count += 1
+        self._update_planning_stats(ms, bool(self.convergence_history[-1]))
+        return trajectory
+
+    # ------------------------------------------------------------------ planner.py:230-280 on the GPU
+    def _solve_se3_mpc(self, current_state: DroneState) -> Dict[str, np.ndarray]:
+        p0 = np.asarray(to_float(current_state.position), dtype=float).reshape(1, 3)
+        v0 = np.asarray(to_float(current_state.velocity), dtype=float).reshape(1, 3)
+        goal = None if self.goal_position is None else np.asarray(self.goal_position, float).reshape(1, 3)
+        res = self._solve_batch(p0, v0, goal, None, self.precision)
+        info = res["info"][0]
+        converged = int(info["status"]) == 0                                     # result.success
+        self.convergence_history.append(converged)
+        self.last_result = dict(nit=int(info["nit"]), nfev=int(info["nfev"]), status=int(info["status"]),
+                                fun=float(info["fun"]), message=TASK_MESSAGES.get(int(info["task"]), ""))
+        if not converged:
+            self.logger.warning("SE(3) MPC optimization did not converge: %s", self.last_result["message"])
+        return {k: res[k][0] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes",
+                                       "body_rates", "thrusts")}
+
+    def _solve_batch(self, p0, v0, goal, x0, precision, want_trajectory=True) -> Dict[str, np.ndarray]:
+        """B problems in one launch; host float64 arrays in, host float64 arrays out."""
+        import torch
+        ops = self._get_ops()
+        dev = ops.be.device
+        dt = torch.float32 if precision == "f32" else torch.float64
+        B, N = p0.shape[0], self.se3_config.prediction_horizon
+        prm = self._params(has_goal=int(goal is not None))
+        pack = np.concatenate([p0, v0] + ([goal] if goal is not None else []), axis=0)
+        dpack = torch.from_numpy(np.ascontiguousarray(pack)).to(device=dev, dtype=dt)
+        dp0, dv0 = dpack[:B], dpack[B:2 * B]
+        dgoal = dpack[2 * B:3 * B] if goal is not None else None
+        dx0 = None if x0 is None else torch.from_numpy(np.ascontiguousarray(x0)).to(device=dev, dtype=dt)
+        out = ops.solve(prm, dp0, dv0, dgoal, x0=dx0, want_trajectory=want_trajectory)
+        x = out["x"].to(torch.float64).cpu().numpy()
+        res = dict(x=x, info=ops.info_to_host(out["info"]),
+                   positions=x[:, :3 * N].reshape(B, N, 3), velocities=x[:, 3 * N:6 * N].reshape(B, N, 3),
+                   thrust_vectors=x[:, 6 * N:].reshape(B, N, 3))
+        if want_trajectory:
+            for k in ("accelerations", "attitudes", "body_rates", "thrusts"):
+                res[k] = out[k].to(torch.float64).cpu().numpy()
+        return res
+
+    # ------------------------------------------------------------------ batched extensions
+    def plan_batch(self, positions, velocities, goals, x0=None, precision: Optional[str] = None) -> Dict[str, np.ndarray]:
+        """Solve B independent problems (the reference would loop plan_trajectory B times).
+        positions, velocities, goals: (B, 3).  Returns arrays with a leading B axis plus ``info``
+        (structured: fun, nit, nfev, status, task)."""
+        p0 = np.asarray(to_float(positions), float).reshape(-1, 3)
+        v0 = np.asarray(to_float(velocities), float).reshape(-1, 3)
+        g = np.asarray(to_float(goals), float).reshape(-1, 3)
+        if not (p0.shape == v0.shape == g.shape):
+            raise ValueError("positions, velocities and goals must all be (B, 3)")
+        return self._solve_batch(p0, v0, g, x0, precision or "f32")
+
+    def plan_with_restarts(self, current_state: DroneState, goal_position, n_restarts: int = 256, sigma: float = 1.0,
+                           seed: int = 0, precision: Optional[str] = None) -> Trajectory:
+        """R cold starts of ONE problem: restart 0 is the reference's straight-line start, restarts
+        1..R-1 add N(0, sigma) newtons to its thrust block (the solver projects into the box);
+        the restart with the lowest final objective wins."""
+        current_state, _, _ = self.sense(current_state, goal_position)
+        N, R = self.se3_config.prediction_horizon, int(n_restarts)
+        p0 = np.tile(np.asarray(to_float(current_state.position), float), (R, 1))
+        v0 = np.tile(np.asarray(to_float(current_state.velocity), float), (R, 1))
+        g = np.tile(self.goal_position, (R, 1))
+        x0 = np.tile(self._cold_start(p0[0], v0[0], self.goal_position), (R, 1))
+        rng = np.random.default_rng(seed)
+        x0[1:, 6 * N:] += rng.normal(0.0, sigma, (R - 1, 3 * N))
+        res = self._solve_batch(p0, v0, g, x0, precision or self.precision)
+        best = int(np.argmin(res["info"]["fun"]))
+        self.last_result = dict(best_restart=best, fun=float(res["info"]["fun"][best]),
+                                fun_cold_start=float(res["info"]["fun"][0]))
+        sol = {k: res[k][best] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes",
+                                         "body_rates", "thrusts")}
+        return self._create_trajectory_from_solution(sol, time.time())
+
+    def _cold_start(self, p0, v0, goal) -> np.ndarray:
+        """planner.py:329-359 on the host (only to seed restarts; the solver has its own)."""
+        N, dt = self.se3_config.prediction_horizon, self.se3_config.dt
+        P = np.zeros((N, 3)); V = np.zeros((N, 3)); T = np.zeros((N, 3))
+        for i in range(N):
+            a = i / max(N - 1, 1)
+            P[i] = (1 - a) * p0 + a * goal
+            if i > 0:
+                V[i] = (P[i] - P[i - 1]) / dt
+        V[0] = v0
+        T[:, 2] = self.hover_thrust
+        return np.concatenate([P.ravel(), V.ravel(), T.ravel()])
+
+    def obstacle_clearance(self, trajectory: Trajectory) -> Dict[str, float]:
+        """planner.py:499-514 evaluated on a planned trajectory with the obstacle kernel: the minimum
+        of |p_k - c_j|^2 - (r_j + margin)^2 over steps and obstacles (>= 0 means clear) and the summed
+        violation.  (The reference builds these constraints and never passes them to the solver.)"""
+        import torch
+        if not self.obstacles:
+            return dict(min_residual=float("inf"), violation=0.0)
+        ops = self._get_ops()
+        N = len(trajectory.positions)
+        X = torch.zeros(9 * N, 1, dtype=torch.float64, device=ops.be.device)
+        X[:3 * N, 0] = torch.from_numpy(np.asarray(trajectory.positions, float).ravel()).to(ops.be.device)
+        sph = torch.tensor([[*c, r] for c, r in self.obstacles], dtype=torch.float64, device=ops.be.device)
+        _, cmin, viol = ops.obstacle_residual(self._params(horizon=N), X, sph, materialize=False)
+        return dict(min_residual=float(cmin[0]), violation=float(viol[0]))
+
+    # ------------------------------------------------------------------ planner.py:656-757
+    def _create_trajectory_from_solution(self, solution: Dict[str, np.ndarray], start_time: float) -> Trajectory:
+        N = len(solution["positions"])
+        timestamps = start_time + np.arange(N) * self.se3_config.dt
+        return Trajectory(timestamps=timestamps, positions=solution["positions"], velocities=solution["velocities"],
+                          accelerations=solution["accelerations"], attitudes=solution["attitudes"],
+                          body_rates=solution["body_rates"], thrusts=solution["thrusts"],
+                          yaws=solution["attitudes"][:, 2], yaw_rates=solution["body_rates"][:, 2])
+
+    def _generate_emergency_trajectory(self, current_state: DroneState) -> Trajectory:
+        self.logger.warning("Generating emergency hover trajectory")
+        N, dt = self.se3_config.prediction_horizon, self.se3_config.dt
+        return Trajectory(timestamps=current_state.timestamp + np.arange(N) * dt,
+                          positions=np.tile(np.asarray(to_float(current_state.position), float), (N, 1)),
+                          velocities=np.zeros((N, 3)), accelerations=np.zeros((N, 3)))
+
+    def get_planning_stats(self) -> Dict[str, Any]:
+        if not self.planning_times:
+            return {}
+        return {"mean_planning_time_ms": float(np.mean(self.planning_times)),
+                "max_planning_time_ms": float(np.max(self.planning_times)),
+                "success_rate": float(np.mean(self.convergence_history)) if self.convergence_history else 0.0,
+                "total_plans": self.plan_count}
+
+    def reset_performance_tracking(self) -> None:
+        self.planning_times.clear()
+        self.convergence_history.clear()
+        self.plan_count = 0
+
+    def is_plan_valid(self, trajectory: Trajectory) -> bool:
+        if trajectory is None or len(trajectory.positions) == 0:
+            return False
+        P = np.asarray(trajectory.positions, float)
+        if np.any(np.isnan(P)) or np.any(np.isinf(P)) or np.any(P[:, 2] < 0.1):
+            return False
+        if trajectory.velocities is not None and np.any(np.abs(np.asarray(trajectory.velocities, float)) > 20.0):
+            return False
+        return True
+
+    def update_plan(self, current_state: DroneState, obstacles: List[Dict[str, Any]]) -> Trajectory:
+        self.clear_obstacles()
+        for ob in obstacles:
+            if "position" in ob and "radius" in ob:
+                self.add_obstacle(np.array(ob["position"], float), ob["radius"])
+        if self.goal_position is not None:
+            return self.plan_trajectory(current_state, self.goal_position)
+        return self._generate_emergency_trajectory(current_state)
+
+    def get_config(self) -> SE3MPCConfig:
+        return self.se3_config
+
+
+PlannerFactory.register("se3_mpc", SE3MPCPlanner)      # planner.py:761-762

@@ -31,3 +31,35 @@ class NumpyBackend:
 
     def to_host(self, a):
         return a
+
+
+class TorchCpuBackend:
+    """CPU torch tensors + the emulated library: lets the CPU suite drive the planner's real host
+    code path (which speaks torch) without a GPU.  TEST INFRASTRUCTURE (the product's TorchBackend
+    refuses CPU tensors)."""
+
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cpu")
+        self._dt = {"f32": torch.float32, "f64": torch.float64, "i32": torch.int32, "i64": torch.int64, "u8": torch.uint8}
+
+    def empty(self, shape, kind):
+        return self.torch.empty(shape, dtype=self._dt[kind])
+
+    def suffix(self, a):
+        return "f32" if a.dtype == self.torch.float32 else "f64"
+
+    def check(self, a, name):
+        if not a.is_contiguous():
+            raise ValueError(f"{name}: tensor must be contiguous")
+        return a
+
+    def ptr(self, a):
+        return 0 if a is None else a.data_ptr()
+
+    def stream(self):
+        return 0
+
+    def to_host(self, a):
+        return a.numpy()

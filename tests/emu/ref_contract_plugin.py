@@ -1,0 +1,18 @@
+"""pytest plugin (TEST INFRASTRUCTURE, build container only): lets the reference's own
+tests/test_planner_controller_contract.py run *in place, unchanged* against this package on a box
+without a GPU by pointing the planner at the host-emulated kernels.  Usage:
+
+  PYTHONPATH=dart_planner_amd/compat:.:tests/emu python -m pytest -c /dev/null --rootdir=/tmp \
+      -p ref_contract_plugin -p no:cacheprovider /root/reference/tests/test_planner_controller_contract.py
+
+On a GPU box drop `-p ref_contract_plugin`: the planner then uses libse3mpc.so."""
+import build_emu
+from numpy_backend import TorchCpuBackend
+
+
+def pytest_configure(config):
+    from dart_planner_amd import capi
+    from dart_planner_amd.ops import Ops
+    from dart_planner_amd.planning import se3_mpc_planner as mod
+    ops = Ops(TorchCpuBackend(), capi.Library(build_emu.build()))
+    mod.SE3MPCPlanner._get_ops = lambda self: ops
