@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--ring", type=int, default=0, help="distinct batches cycled through (0 = enough to exceed 512 MiB)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solve", action="store_true", help="skip the p95 solve-latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--variant", type=int, default=0, help="se3mpc_set_rollout_variant (0 = auto)")
     ap.add_argument("--sweep", action="store_true", help="also time saturating batch sizes (extra keys)")
@@ -97,15 +98,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    from dart_planner_amd.distributed import allreduce_min_keys, init_distributed
+    init_distributed("nccl", device=dev)
     if a.gpus != world and rank == 0:
         print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1", file=sys.stderr)
 
@@ -119,15 +117,17 @@ def main():
     slot_bytes = 4 * B * ((9 + 3 * N) + (1 + 3 * N))
     ring = a.ring if a.ring > 0 else max(2, math.ceil(512 * 2 ** 20 / slot_bytes))
     p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=3 + rank)
-    keys = torch.full((max(K, W, 1),), -1, dtype=torch.int64, device=dev)     # UINT64_MAX
+    keys = torch.full((max(K, 1),), -1, dtype=torch.int64, device=dev)        # UINT64_MAX
+    wkeys = torch.full((max(W, 1),), -1, dtype=torch.int64, device=dev)
     base = rank * B
 
-    def step(i):
+    def step(i, kbuf=None):
         s = i % ring
-        ops.rollout_cost_grad(prm, p0[s], v0[s], goal[s], T[s], out=(cost[s], grad[s]), key=keys[i:i + 1], index_base=base)
+        kb = keys if kbuf is None else kbuf
+        ops.rollout_cost_grad(prm, p0[s], v0[s], goal[s], T[s], out=(cost[s], grad[s]), key=kb[i:i + 1], index_base=base)
 
     for i in range(W):                                          # untimed warm-up (eager)
-        step(i)
+        step(i, wkeys)
     torch.cuda.synchronize()
     keys.fill_(-1)
 
@@ -160,11 +160,7 @@ def main():
             step(i)
     e1.record()
     if world > 1:
-        # the single exchange: bucketed all-reduce(MIN) of the K packed keys (sign bit flipped so the
-        # signed int64 order RCCL reduces in equals the unsigned key order)
-        skeys = keys[:K] ^ torch.iinfo(torch.int64).min
-        dist.all_reduce(skeys, op=dist.ReduceOp.MIN)
-        keys[:K] = skeys ^ torch.iinfo(torch.int64).min
+        allreduce_min_keys(keys)     # the single exchange: ONE bucketed all-reduce(MIN) of the K packed keys
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,8 +173,10 @@ def main():
     elapsed = float(el.item())
     kernel_ms = e0.elapsed_time(e1) / K                        # launch-to-launch time of the dominant kernel
     # sanity: every step produced a key that indexes into the global batch
-    kh = keys[:K].cpu().numpy().astype(np.uint64)
+    kh = keys[:K].cpu().numpy().view(np.uint64)
     idx_ok = bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B)))
+
+    solve_stats = None if a.no_solve else solve_leg(torch, ops, dev, B, N, rank, world)
 
     if rank == 0:
         achieved = bytes_per_rollout * B / (kernel_ms * 1e-3) / 1e9
@@ -201,6 +199,8 @@ def main():
                                  "time over the timed region (HIP events around the K launches on the launch stream)"},
             "keys_valid": idx_ok,
         }
+        if solve_stats is not None:
+            res["solve"] = solve_stats
         if a.sweep:
             res["sweep"] = sweep(torch, ops, prm, dev, N)
         if world == 1 and not a.no_cpu_baseline:
@@ -209,6 +209,57 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def solve_leg(torch, ops, dev, B, N, rank, world):
+    """p95 of the per-call wall time (np.percentile convention of the reference's
+    tests/test_real_time_latency.py:296-304; >= 200 timed calls after >= 20 warm-ups, device
+    synchronised inside the timed region) of (a) ONE hover->waypoint solve through the planner mirror
+    (`plan_trajectory`, what the contract test times) and (b) the batched solve of `B` problems in one
+    launch.  Every rank runs its own shard; rank 0 reports."""
+    import torch.distributed as dist
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd.common.types import DroneState
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCConfig, SE3MPCPlanner
+    out = {}
+    for prec in ("f64", "f32"):
+        pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N), precision=prec, device=dev)
+        st = DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.zeros(3))
+        rng = np.random.default_rng(0)
+        goals = rng.uniform(-5, 5, (240, 3)); goals[:, 2] = np.abs(goals[:, 2]) + 0.5
+        ts = []
+        for i, g in enumerate(goals):
+            t0 = time.perf_counter()
+            pl.plan_trajectory(st, g)
+            torch.cuda.synchronize()
+            if i >= 20:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        out[f"single_{prec}"] = {"horizon": N, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
+                                 "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(np.max(ts))}
+    prm = Params.reference_defaults(horizon=N)
+    g = torch.Generator(device=dev); g.manual_seed(100 + rank)
+    p0 = torch.rand(B, 3, device=dev, generator=g) * 40 - 20
+    v0 = torch.rand(B, 3, device=dev, generator=g) * 10 - 5
+    goal = torch.rand(B, 3, device=dev, generator=g) * 40 - 20
+    ts = []
+    nfev = None
+    for i in range(220):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = ops.solve(prm, p0, v0, goal)
+        torch.cuda.synchronize()
+        if i >= 20:
+            ts.append((time.perf_counter() - t0) * 1e3)
+    info = ops.info_to_host(o["info"])
+    mean_ms = float(np.mean(ts))
+    agg = torch.tensor([B / (mean_ms * 1e-3)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg)
+    out["batch_f32"] = {"horizon": N, "batch_per_gpu": B, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
+                        "p95_ms": float(np.percentile(ts, 95)), "solves_per_s": float(agg.item()),
+                        "mean_nfev": float(info["nfev"].mean()), "mean_nit": float(info["nit"].mean()),
+                        "rollouts_inside_solves_per_s": float(agg.item() * info["nfev"].mean())}
+    return out
 
 
 def sweep(torch, ops, prm, dev, N):

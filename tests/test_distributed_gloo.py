@@ -1,0 +1,73 @@
+"""world_size-2 `gloo` test of the multi-GPU path on CPU: restarts sharded over two ranks, packed-key
+all-reduce(MIN), winner broadcast -- must equal the single-process answer over all restarts.
+(Kernels: the product sources compiled for the host, tests/emu.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "emu"))
+
+
+def _ops():
+    import build_emu
+    from numpy_backend import TorchCpuBackend
+    from dart_planner_amd import capi
+    from dart_planner_amd.ops import Ops
+    return Ops(TorchCpuBackend(), capi.Library(build_emu.build()))
+
+
+PROBLEM = dict(p0=[1.0, -2.0, 1.5], v0=[0.2, 0.0, -0.1], goal=[4.0, 1.0, 3.0])
+R_TOTAL = 5
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd import distributed as D
+    D.init_distributed("gloo")
+    res = D.sharded_restart_solve(_ops(), Params.reference_defaults(horizon=6), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"],
+                                  n_restarts=R_TOTAL, sigma=3.0, seed=4, precision="f64")
+    # bucketed key exchange as bench.py does it: K keys, one collective
+    raw = [((0x80000000 | (100 + 7 * rank)) << 32) | (10 * rank + 1), ((0x80000000 | (50 - rank)) << 32) | (10 * rank + 2)]
+    keys = torch.from_numpy(np.array(raw, dtype=np.uint64).view(np.int64).copy())
+    D.allreduce_min_keys(keys)
+    q.put((rank, res["restart"], res["owner"], res["cost"], res["x"], keys.numpy().view(np.uint64).tolist()))
+    torch.distributed.destroy_process_group()
+
+
+def test_shard_bounds():
+    from dart_planner_amd.distributed import shard_bounds
+    for total in (0, 1, 5, 8, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            b = [shard_bounds(total, r, world) for r in range(world)]
+            assert b[0][0] == 0 and b[-1][1] == total and all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_restart_argmin_matches_single_process():
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd import distributed as D
+    single = D.sharded_restart_solve(_ops(), Params.reference_defaults(horizon=6), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"],
+                                     n_restarts=R_TOTAL, sigma=3.0, seed=4, precision="f64")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, restart, owner, cost, x, keys in got:
+        assert restart == single["restart"] and cost == single["cost"]
+        assert np.array_equal(x, single["x"])
+        assert owner == (0 if restart < 3 else 1)                      # shards: rank 0 -> [0,3), rank 1 -> [3,5)
+        # MIN of the unsigned keys: step 0 -> rank 0's (cost bits 100), step 1 -> rank 1's (cost bits 49)
+        assert keys == [((0x80000000 | 100) << 32) | 1, ((0x80000000 | 49) << 32) | 12]
