@@ -180,6 +180,7 @@ def main():
 
     if rank == 0:
         achieved = bytes_per_rollout * B / (kernel_ms * 1e-3) / 1e9
+        traffic = profiled_traffic(B, N)
         res = {
             "metric": "SE(3) rollouts/sec (N=30, batch=8192) + p95 solve ms, at 1/2/4/8 MI355X",
             "value": world * B * K / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -192,8 +193,9 @@ def main():
                        "horizon": N, "batch_per_gpu": B, "global_batch": world * B, "ring": ring,
                        "parallelism": f"batch-sharded x{world}, one bucketed all-reduce(MIN) of {K} keys"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "rollout_reg_kernel<float,30,grad>", "kernel_us": kernel_ms * 1e3,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None if traffic is None else traffic[0],
+                         "traffic_source": None if traffic is None else f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                         "kernel": "se3mpc::rollout_kernel<float, 30, REG, SPLIT, GRAD>", "kernel_us": kernel_ms * 1e3,
                          "bytes_per_launch": bytes_per_rollout * B,
                          "note": "achieved = algorithmic bytes (4*(6N+10) B/rollout x batch) / average launch-to-launch "
                                  "time over the timed region (HIP events around the K launches on the launch stream)"},
@@ -260,6 +262,23 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
                         "mean_nfev": float(info["nfev"].mean()), "mean_nit": float(info["nit"].mean()),
                         "rollouts_inside_solves_per_s": float(agg.item() * info["nfev"].mean())}
     return out
+
+
+def profiled_traffic(B, N):
+    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, same command
+    without the graph) -- PMC counters cannot be read from inside this process.  None if no profile
+    of this exact workload is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("batch") == B and d.get("horizon") == N:
+            best = (float(d["traffic_bytes_per_launch"]), os.path.basename(f))
+    return best
 
 
 def sweep(torch, ops, prm, dev, N):

@@ -7,6 +7,9 @@
 
 #include "se3mpc_common.hpp"
 
+static_assert(sizeof(se3mpc_params) == 160, "se3mpc_params is part of the C ABI (dart_planner_amd/capi.py mirrors it)");
+static_assert(sizeof(se3mpc_solve_info) == 24, "se3mpc_solve_info is part of the C ABI");
+
 namespace se3mpc {
 
 static thread_local char g_last_error[256] = "";
