@@ -132,7 +132,7 @@ def _closed_loop(r: Rig, simulator, steps, gust_at=None):
     tr = r.planner.plan_trajectory(r.initial_state, r.goal_position)
     # These three cases compare the state's clock (set in setUp) with the plan's wall-clock stamps, so
     # their outcome depends on how long planning took: ~2 ms on the reference, ~1 ms on the GPU, but
-    # seconds under the CPU emulation (one OS thread per lane).  Cap the apparent latency at 2 ms so
+    # ~0.1-0.3 s under the CPU emulation.  Cap the apparent latency at 2 ms so
     # the emulated run sees the same 12.5 ms plan window the reference's own run sees.
     latency = tr.timestamps[0] - t_before
     if latency > 0.002:

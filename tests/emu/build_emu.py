@@ -18,7 +18,7 @@ def build(force: bool = False) -> str:
     deps = [d for d in deps if os.path.exists(d)]
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
-    cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-pthread", "-ffp-contract=off",
+    cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off",
            "-Wno-unknown-pragmas", "-Wno-attributes",
            "-I" + HERE, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     for s in srcs:

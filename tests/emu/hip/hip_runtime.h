@@ -2,12 +2,12 @@
 // dart_planner_amd/csrc/*.hip uses.  It shadows <hip/hip_runtime.h> when tests/emu/build_emu.py
 // compiles the UNMODIFIED product sources with g++ into tests/emu/libse3mpc_emu.so, so that the
 // kernels' arithmetic and the C-ABI argument handling can be checked against the oracle on a
-// machine without a GPU (`pytest -m "not gpu"`).  One std::thread per lane of a workgroup,
-// workgroups run one after another; __syncthreads()/__shfl*() rendezvous on a std::barrier.
+// machine without a GPU (`pytest -m "not gpu"`).  One user-level fiber (ucontext) per lane of a
+// workgroup, workgroups run one after another; __syncthreads()/__shfl*() are rendezvous points.
 // Never shipped, never loaded by the product (dart_planner_amd loads libse3mpc.so only).
 #pragma once
 #include <algorithm>
-#include <barrier>
+#include <ucontext.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -45,22 +45,68 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->gcnArchNa
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 
 namespace emu {
-inline thread_local dim3 t_threadIdx, t_blockIdx, t_blockDim, t_gridDim;
-inline std::barrier<>* g_barrier = nullptr;
+// Lanes are user-level fibers (ucontext) scheduled round-robin on the calling OS thread: a lane runs
+// until it reaches a rendezvous (__syncthreads / a cross-lane op) or returns, then yields.  No OS
+// scheduling is involved, so a 64-lane workgroup with thousands of rendezvous runs in milliseconds.
+struct Fiber {
+  ucontext_t ctx;
+  dim3 tid;
+  bool done = false;
+  std::vector<unsigned char> stack;
+};
+inline std::vector<Fiber> g_fibers;
+inline ucontext_t g_main;
+inline int g_cur = 0, g_live = 0;
+inline unsigned g_arrived = 0, g_generation = 0;
+inline dim3 g_blockIdx, g_blockDim, g_gridDim;
+inline std::function<void()> g_body;
 inline unsigned char g_dyn_lds[163840] __attribute__((aligned(64)));
 inline unsigned long long g_slots[1024];
 
-inline void sync() { g_barrier->arrive_and_wait(); }
+inline void yield_to_next() {
+  const int n = (int)g_fibers.size();
+  int nxt = g_cur;
+  for (int i = 1; i <= n; ++i) {
+    const int c = (g_cur + i) % n;
+    if (!g_fibers[c].done) { nxt = c; break; }
+  }
+  if (nxt == g_cur) return;
+  const int prev = g_cur;
+  g_cur = nxt;
+  swapcontext(&g_fibers[prev].ctx, &g_fibers[nxt].ctx);
+}
+
+// barrier over the lanes that are still running (a lane that returned has dropped out, as
+// std::barrier::arrive_and_drop would)
+inline void sync() {
+  const unsigned gen = g_generation;
+  if (++g_arrived >= (unsigned)g_live) { g_arrived = 0; ++g_generation; return; }
+  while (g_generation == gen) yield_to_next();
+}
+
+inline void fiber_entry() {
+  g_body();
+  Fiber& f = g_fibers[g_cur];
+  f.done = true;
+  --g_live;
+  if (g_live > 0 && g_arrived >= (unsigned)g_live) { g_arrived = 0; ++g_generation; }   // release waiters
+  if (g_live == 0) { swapcontext(&f.ctx, &g_main); return; }
+  const int n = (int)g_fibers.size();
+  for (int i = 1; i <= n; ++i) {
+    const int c = (g_cur + i) % n;
+    if (!g_fibers[c].done) { g_cur = c; setcontext(&g_fibers[c].ctx); }
+  }
+}
 
 template <typename T>
 inline T exchange(T v, int src_lane_in_block) {
   static_assert(sizeof(T) <= 8, "emu shuffle: <= 8 bytes");
-  const unsigned me = t_threadIdx.x;
+  const unsigned me = g_fibers[g_cur].tid.x;
   unsigned long long raw = 0;
   std::memcpy(&raw, &v, sizeof(T));
   g_slots[me] = raw;
   sync();
-  unsigned long long got = (src_lane_in_block >= 0 && src_lane_in_block < (int)t_blockDim.x) ? g_slots[src_lane_in_block] : raw;
+  unsigned long long got = (src_lane_in_block >= 0 && src_lane_in_block < (int)g_blockDim.x) ? g_slots[src_lane_in_block] : raw;
   sync();
   T out;
   std::memcpy(&out, &got, sizeof(T));
@@ -69,28 +115,34 @@ inline T exchange(T v, int src_lane_in_block) {
 
 template <typename K, typename... Args>
 void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+  constexpr size_t kStack = 1 << 20;
+  g_blockDim = block; g_gridDim = grid;
+  g_body = [=]() { kernel(args...); };
+  if (g_fibers.size() != block.x) g_fibers.assign(block.x, Fiber());
   for (unsigned by = 0; by < grid.y; ++by)
     for (unsigned bx = 0; bx < grid.x; ++bx) {
-      std::barrier<> bar(block.x);
-      g_barrier = &bar;
-      std::vector<std::thread> th;
-      th.reserve(block.x);
-      for (unsigned t = 0; t < block.x; ++t)
-        th.emplace_back([=, &bar]() {
-          t_threadIdx = dim3(t); t_blockIdx = dim3(bx, by); t_blockDim = block; t_gridDim = grid;
-          kernel(args...);
-          bar.arrive_and_drop();
-        });
-      for (auto& x : th) x.join();
+      g_blockIdx = dim3(bx, by);
+      g_arrived = 0; g_generation = 0; g_live = (int)block.x;
+      for (unsigned t = 0; t < block.x; ++t) {
+        Fiber& f = g_fibers[t];
+        f.tid = dim3(t); f.done = false;
+        if (f.stack.size() != kStack) f.stack.resize(kStack);
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = &g_main;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+      }
+      g_cur = 0;
+      swapcontext(&g_main, &g_fibers[0].ctx);
     }
-  g_barrier = nullptr;
 }
 }  // namespace emu
 
-#define threadIdx (::emu::t_threadIdx)
-#define blockIdx (::emu::t_blockIdx)
-#define blockDim (::emu::t_blockDim)
-#define gridDim (::emu::t_gridDim)
+#define threadIdx (::emu::g_fibers[::emu::g_cur].tid)
+#define blockIdx (::emu::g_blockIdx)
+#define blockDim (::emu::g_blockDim)
+#define gridDim (::emu::g_gridDim)
 
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::emu::launch(kernel, grid, block, __VA_ARGS__)
 
@@ -113,9 +165,7 @@ inline T __shfl(T v, int src, int width = 64) {
   return ::emu::exchange(v, me - lane + (src % width));
 }
 inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v) {
-  static std::mutex* m = new std::mutex;   // blocks run sequentially; lanes of a block may race
-  std::lock_guard<std::mutex> g(*m);
-  unsigned long long old = *p;
+  unsigned long long old = *p;             // fibers are cooperative: no preemption inside this function
   if (v < old) *p = v;
   return old;
 }

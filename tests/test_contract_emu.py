@@ -28,7 +28,7 @@ def attach():
 def test_contract_case(attach, case):
     rig = cc.Rig(attach)
     if case is cc.case_performance_benchmark:
-        case(rig, plan_ms=60000.0)      # the emulation runs one OS thread per lane: the 50 ms bound is for the GPU suite
+        case(rig, plan_ms=60000.0)      # the emulation is a single host thread: the 50 ms bound is for the GPU suite
     else:
         case(rig)
 

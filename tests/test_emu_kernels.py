@@ -1,7 +1,7 @@
 """CPU suite: the UNMODIFIED product kernels (dart_planner_amd/csrc/*.hip) compiled for the host by
 tests/emu (one std::thread per lane) and driven through the same C ABI and the same Ops front-end
 as on the GPU, checked against the oracle and the reference's golden vectors.  This is test
-infrastructure to debug kernel arithmetic and host logic without a GPU; the product never loads
+infrastructure (lanes are fibers) to debug kernel arithmetic and host logic without a GPU; the product never loads
 tests/emu/libse3mpc_emu.so, and the `-m gpu` suite repeats every check on the real library."""
 import os
 import sys
@@ -42,8 +42,10 @@ def test_lane_kernels_other_dt(emu_ops):
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_solver_reproduces_reference_solves(emu_ops, golden_solve, dt):
     data, meta = golden_solve
-    # contract case, a 3-iteration case, N = 1, N = 2, the box-clipped start and one ABNORMAL line search
-    worst = pc.check_solver_golden(harness(emu_ops, dt), data, meta, keys={"s00_", "s01_", "s26_", "s31_", "s32_", "s33_"})
+    # f64: every solve the reference produced; f32: every other one (contract case, N = 1/2, box-clipped
+    # starts, dt = 0.1, ABNORMAL line searches are in both halves)
+    keys = None if dt == np.float64 else {c["key"] for i, c in enumerate(meta["cases"]) if i % 2 == 0 or c["tag"] != "random"}
+    worst = pc.check_solver_golden(harness(emu_ops, dt), data, meta, keys=keys)
     assert worst <= (1e-4 if dt == np.float32 else 1e-9)
 
 
