@@ -7,12 +7,18 @@ RCCL).  Rank 0 prints ONE JSON line.
 
 A *step* is one pass of the hot path over one batch: the shooting-form rollout + running/terminal
 cost + exact thrust gradient (SURVEY.md section 8d "canonical rollout", 4*(6N+10) B per rollout) of
-``batch`` synthetic trajectories resident in HBM, with the batch argmin folded into the same
+``batch`` = 8192 synthetic trajectories resident in HBM, with the batch argmin folded into the same
 kernel.  The batch is fixed per GPU (weak scaling); the only cross-GPU exchange is ONE bucketed
 RCCL all-reduce(MIN) of the K packed (cost, index) keys at the end of the timed region
 (SURVEY.md section 8e).  Steps cycle through a ring of distinct input/output batches larger than the
-256 MiB Infinity Cache, so every step streams its operands from HBM; the K launches are
-captured once into a hipGraph (launch-bound inner loop) and replayed inside the timed region.
+256 MiB Infinity Cache, so every step streams its operands from HBM.
+
+Two legs time the same K steps (SURVEY.md section 7 "report both"):
+  * primary (`value`, `roofline`): the steps are independent batches (a Monte-Carlo sweep, many
+    planners), so `--steps-per-launch` S = 64 of them go into ONE multi-batch kernel launch (grid.y);
+  * `single_launch`: one kernel launch per 8192-rollout step (sequentially dependent sampling
+    iterations of one planner): 6 MB per launch = 1 us of HBM time, i.e. latency-bound.
+Launches are captured once into a hipGraph and replayed inside the timed region.
 """
 import argparse
 import json
@@ -42,6 +48,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the p95 solve-latency leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--steps-per-launch", type=int, default=64,
+                    help="independent 8192-rollout steps issued as ONE multi-batch kernel launch (1 = one launch per step)")
+    ap.add_argument("--no-single", action="store_true", help="skip the one-launch-per-step leg")
     ap.add_argument("--variant", type=int, default=0, help="se3mpc_set_rollout_variant (0 = auto)")
     ap.add_argument("--sweep", action="store_true", help="also time saturating batch sizes (extra keys)")
     return ap.parse_args()
@@ -91,6 +100,48 @@ def cpu_baseline(B, N, seconds):
                 reference_shaped_evals_per_s=m / el1, host_cpus=os.cpu_count())
 
 
+def timed_region(torch, dist, world, dev, K, launch_all, graph, keys, allreduce_min_keys):
+    """The contract's timed region: barrier + synchronize, K steps, [one bucketed all-reduce(MIN) of the
+    K keys], synchronize + barrier; MAX over ranks.  Returns (elapsed_s, device_ms between the HIP events
+    that bracket the K steps on the launch stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    if graph is not None:
+        graph.replay()
+    else:
+        launch_all()
+    e1.record()
+    if world > 1:
+        allreduce_min_keys(keys)     # the single exchange: ONE bucketed all-reduce(MIN) of the K packed keys
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    return float(el.item()), e0.elapsed_time(e1)
+
+
+def capture(torch, dev, fn):
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph.replay()                                              # one untimed replay (uploads the graph)
+    torch.cuda.synchronize()
+    return graph
+
+
 def main():
     a = parse()
     import torch
@@ -111,96 +162,86 @@ def main():
     from dart_planner_amd.ops import Ops, TorchBackend
     ops = Ops(TorchBackend(dev))
     ops.lib.set_rollout_variant(a.variant)
-    B, N, K, W = a.batch, a.horizon, a.steps, a.warmup
+    B, N, K, W, S = a.batch, a.horizon, a.steps, a.warmup, max(1, a.steps_per_launch)
     prm = Params.reference_defaults(horizon=N)
     bytes_per_rollout = 4 * (6 * N + 10)
     slot_bytes = 4 * B * ((9 + 3 * N) + (1 + 3 * N))
     ring = a.ring if a.ring > 0 else max(2, math.ceil(512 * 2 ** 20 / slot_bytes))
+    ring = S * max(2, math.ceil(ring / S))                     # whole launches, consecutive launches on disjoint slots
     p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=3 + rank)
     keys = torch.full((max(K, 1),), -1, dtype=torch.int64, device=dev)        # UINT64_MAX
-    wkeys = torch.full((max(W, 1),), -1, dtype=torch.int64, device=dev)
+    wkeys = torch.full((max(W, S),), -1, dtype=torch.int64, device=dev)
     base = rank * B
 
-    def step(i, kbuf=None):
-        s = i % ring
-        kb = keys if kbuf is None else kbuf
-        ops.rollout_cost_grad(prm, p0[s], v0[s], goal[s], T[s], out=(cost[s], grad[s]), key=kb[i:i + 1], index_base=base)
+    def launch(i0, n, kbuf):
+        """steps i0 .. i0+n-1 (n <= S consecutive ring slots) as ONE launch"""
+        s0 = i0 % ring
+        if n == 1:
+            ops.rollout_cost_grad(prm, p0[s0], v0[s0], goal[s0], T[s0], out=(cost[s0], grad[s0]), key=kbuf[i0:i0 + 1], index_base=base)
+        else:
+            ops.rollout_cost_grad_batched(prm, p0[s0:s0 + n], v0[s0:s0 + n], goal[s0:s0 + n], T[s0:s0 + n], cost[s0:s0 + n],
+                                          grad[s0:s0 + n], keys=kbuf[i0:i0 + n], index_base=base)
 
-    for i in range(W):                                          # untimed warm-up (eager)
-        step(i, wkeys)
-    torch.cuda.synchronize()
-    keys.fill_(-1)
+    def run_steps(nsteps, per_launch, kbuf):
+        i = 0
+        while i < nsteps:
+            n = min(per_launch, nsteps - i)
+            n = min(n, ring - (i % ring))
+            launch(i, n, kbuf)
+            i += n
 
-    graph = None
-    if not a.no_graph:
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
-                for i in range(K):
-                    step(i)
-        torch.cuda.current_stream().wait_stream(side)
+    results = {}
+    for mode, per in (("primary", S), ("single_launch", 1)):
+        if mode == "single_launch" and (S == 1 or a.no_single):
+            continue
+        run_steps(W, per, wkeys)                                # untimed warm-up (eager)
         torch.cuda.synchronize()
-        graph.replay()                                          # one untimed replay (uploads the graph)
-        torch.cuda.synchronize()
+        graph = None if a.no_graph else capture(torch, dev, lambda: run_steps(K, per, keys))
         keys.fill_(-1)
         torch.cuda.synchronize()
-
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    e0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        for i in range(K):
-            step(i)
-    e1.record()
-    if world > 1:
-        allreduce_min_keys(keys)     # the single exchange: ONE bucketed all-reduce(MIN) of the K packed keys
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-
-    el = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    kernel_ms = e0.elapsed_time(e1) / K                        # launch-to-launch time of the dominant kernel
-    # sanity: every step produced a key that indexes into the global batch
-    kh = keys[:K].cpu().numpy().view(np.uint64)
-    idx_ok = bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B)))
+        elapsed, dev_ms = timed_region(torch, dist, world, dev, K, lambda: run_steps(K, per, keys), graph, keys, allreduce_min_keys)
+        nlaunch = sum(1 for _ in _launch_sizes(K, per, ring))
+        kh = keys[:K].cpu().numpy().view(np.uint64)
+        results[mode] = dict(elapsed=elapsed, launch_ms=dev_ms / nlaunch, nlaunch=nlaunch, per=per, graph=graph is not None,
+                             keys_valid=bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B))))
+        del graph
 
     solve_stats = None if a.no_solve else solve_leg(torch, ops, dev, B, N, rank, world)
 
     if rank == 0:
-        achieved = bytes_per_rollout * B / (kernel_ms * 1e-3) / 1e9
-        traffic = profiled_traffic(B, N)
+        r = results["primary"]
+        per_launch_rollouts = B * min(S, K)
+        achieved = bytes_per_rollout * per_launch_rollouts / (r["launch_ms"] * 1e-3) / 1e9
+        traffic = profiled_traffic(B, N, S)
         res = {
             "metric": "SE(3) rollouts/sec (N=30, batch=8192) + p95 solve ms, at 1/2/4/8 MI355X",
-            "value": world * B * K / elapsed, "unit": "rollouts/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": world * B * K / r["elapsed"], "unit": "rollouts/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": r["elapsed"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"horizon={N} SE(3) rollout + cost + thrust-gradient (+ fused batch argmin), "
-                                   f"batch={B} per GPU per step, ring of {ring} distinct batches in HBM "
-                                   f"({ring * slot_bytes / 2 ** 20:.0f} MiB), "
-                                   f"{'hipGraph replay of K launches' if graph is not None else 'eager launches'}",
-                       "horizon": N, "batch_per_gpu": B, "global_batch": world * B, "ring": ring,
+                                   f"batch={B} per GPU per step, {S} independent steps per kernel launch "
+                                   f"({'one multi-batch launch = grid.y' if S > 1 else 'one launch per step'}), "
+                                   f"ring of {ring} distinct batches in HBM ({ring * slot_bytes / 2 ** 20:.0f} MiB), "
+                                   f"{'hipGraph replay' if r['graph'] else 'eager launches'}",
+                       "horizon": N, "batch_per_gpu": B, "global_batch": world * B, "steps_per_launch": S, "ring": ring,
                        "parallelism": f"batch-sharded x{world}, one bucketed all-reduce(MIN) of {K} keys"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None if traffic is None else traffic[0],
                          "traffic_source": None if traffic is None else f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-                         "kernel": "se3mpc::rollout_kernel<float, 30, REG, SPLIT, GRAD>", "kernel_us": kernel_ms * 1e3,
-                         "bytes_per_launch": bytes_per_rollout * B,
-                         "note": "achieved = algorithmic bytes (4*(6N+10) B/rollout x batch) / average launch-to-launch "
-                                 "time over the timed region (HIP events around the K launches on the launch stream)"},
-            "keys_valid": idx_ok,
+                         "kernel": "se3mpc::rollout_kernel<float, 30, REG, SPLIT, GRAD>", "kernel_us": r["launch_ms"] * 1e3,
+                         "launches": r["nlaunch"], "rollouts_per_launch": per_launch_rollouts,
+                         "bytes_per_launch": bytes_per_rollout * per_launch_rollouts,
+                         "note": "achieved = algorithmic bytes (4*(6N+10) B/rollout x rollouts per launch) / average "
+                                 "launch duration (HIP events around the launches of the timed region on the launch stream)"},
+            "keys_valid": r["keys_valid"],
         }
+        if "single_launch" in results:
+            q = results["single_launch"]
+            g1 = bytes_per_rollout * B / (q["launch_ms"] * 1e-3) / 1e9
+            res["single_launch"] = {"what": "the same K steps, ONE kernel launch per 8192-rollout step (sequentially dependent iterations)",
+                                    "value": world * B * K / q["elapsed"], "ms_per_step": q["elapsed"] / K * 1e3,
+                                    "kernel_us": q["launch_ms"] * 1e3, "achieved_GB_per_s": g1, "frac": g1 / HBM_PEAK_GBPS,
+                                    "keys_valid": q["keys_valid"]}
         if solve_stats is not None:
             res["solve"] = solve_stats
         if a.sweep:
@@ -211,6 +252,14 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _launch_sizes(nsteps, per_launch, ring):
+    i = 0
+    while i < nsteps:
+        n = min(per_launch, nsteps - i, ring - (i % ring))
+        yield n
+        i += n
 
 
 def solve_leg(torch, ops, dev, B, N, rank, world):
@@ -264,7 +313,7 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
     return out
 
 
-def profiled_traffic(B, N):
+def profiled_traffic(B, N, S):
     """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes
     (profiles/rNN_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, same command
     without the graph) -- PMC counters cannot be read from inside this process.  None if no profile
@@ -276,7 +325,7 @@ def profiled_traffic(B, N):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("batch") == B and d.get("horizon") == N:
+        if d.get("batch") == B and d.get("horizon") == N and d.get("steps_per_launch", 1) == S:
             best = (float(d["traffic_bytes_per_launch"]), os.path.basename(f))
     return best
 

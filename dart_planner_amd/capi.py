@@ -96,6 +96,7 @@ _TYPED_API = {
     "physical_constraints": (True, [_I, _I, _P, _P, _P]),
     "extract": (True, [_I, _I, _P, _P, _P, _P, _P, _P]),
     "rollout_cost_grad": (True, [_I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
+    "rollout_cost_grad_batched": (True, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
     "is_plan_valid": (True, [_I, _I, _P, _P, _P, _P]),
     "argmin": (False, [_I, _P, C.c_uint32, _P, _P]),
     "transpose": (False, [_I, _I, _P, _I, _P, _I, _P]),

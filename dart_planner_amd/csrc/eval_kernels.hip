@@ -284,8 +284,13 @@ __device__ __forceinline__ void rollout_epilogue(bool live, int b, R c, R* __res
   const uint32_t bits = live ? orderable_bits((float)c) : 0xFFFFFFFFu;
   const uint32_t m = wave_min_u32(bits);
   const int src = first_lane(wave_ballot(live && bits == m));
-  if (key != nullptr && src >= 0 && lane_id() == src)
-    atomicMin(key, ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b));
+  if (key != nullptr && src >= 0 && lane_id() == src) {
+    // *key only ever decreases, so a (possibly stale, hence too large) plain read can only cause a
+    // redundant atomic, never skip a needed one: of W wavefronts only O(log W) issue the atomic, which
+    // removes the single-address contention a 65536-wavefront batch would otherwise serialise on.
+    const unsigned long long mine = ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b);
+    if (mine < *reinterpret_cast<volatile unsigned long long*>(key)) atomicMin(key, mine);
+  }
 }
 
 template <typename R>
@@ -331,7 +336,7 @@ __device__ __forceinline__ R axis_cost(const DevParams<R>& q, const RolloutSums<
 
 // One axis of one trajectory with exact-N register arrays.  Loads of all N thrust rows are issued
 // back to back (N independent HBM requests in flight per lane) before the first use.
-template <typename R, int N, bool GRAD, bool STATES>
+template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0>
 __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
@@ -339,7 +344,7 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
   R t[N], es[N], vs[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    t[k] = lane_ld(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
+    t[k] = lane_ld<LDAUX>(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
   }
   const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
   R p = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
@@ -364,12 +369,12 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
   if (GRAD) {
     R lamP = c.two_wp * ((R)1 + q.term) * es[N - 1];
     R lamV = c.two_wv * vs[N - 1];
-    lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (t[N - 1] * q.inv_mass - c.grav) + c.c_tt * (t[N - 1] - c.hov));
+    lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (t[N - 1] * q.inv_mass - c.grav) + c.c_tt * (t[N - 1] - c.hov));
 #pragma unroll
     for (int k = N - 2; k >= 0; --k) {
       const R acc = t[k] * q.inv_mass - c.grav;
       const R dev = t[k] - c.hov;
-      lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
+      lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
       lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
       lamP = c.two_wp * es[k] + lamP;
     }
@@ -379,7 +384,7 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
 
 // Any N, O(1) registers: the reverse sweep re-reads T_k (L2) and walks the states backwards
 // through the inverted recurrence instead of storing them.
-template <typename R, bool GRAD, bool STATES>
+template <typename R, bool GRAD, bool STATES, int STAUX = 0>
 __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
@@ -410,7 +415,7 @@ __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsi
   if (GRAD) {
     R lamP = c.two_wp * ((R)1 + q.term) * (pl - c.gl);
     R lamV = c.two_wv * vl;
-    lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (tk * q.inv_mass - c.grav) + c.c_tt * (tk - c.hov));
+    lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (tk * q.inv_mass - c.grav) + c.c_tt * (tk - c.hov));
     R pk = pl, vk = vl;
 #pragma unroll 6
     for (int k = N - 2; k >= 0; --k) {
@@ -419,7 +424,7 @@ __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsi
       const R dev = t - c.hov;
       vk = vk - acc * q.dt;                                 // V_k from V_{k+1}
       pk = pk - vk * q.dt - q.half_dt2 * acc;               // P_k from P_{k+1}
-      lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
+      lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
       lamV = c.two_wv * vk + q.dt * lamP + lamV;
       lamP = c.two_wp * (pk - c.gl) + lamP;
     }
@@ -430,13 +435,26 @@ __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsi
 // Kernel shells.  SPLIT: a 192-thread workgroup owns 64 trajectories, wavefront w = axis w; the
 // three partial costs meet in LDS ([3][64] values), then every wavefront runs the (uniform)
 // epilogue and wavefront 0 commits it.  !SPLIT: one wavefront per 64 trajectories loops the axes.
-template <typename R, int N, bool REG, bool SPLIT, bool GRAD, bool STATES>
+// blockIdx.y = batch index of a multi-batch launch: consecutive batches are consecutive [rows][ld]
+// blocks of every operand (keys: one word per batch).  FLAGS: bit 0 nt loads of T, bit 1 nt stores of
+// the gradient, bit 2 XCD-contiguous block order (blocks that share an XCD stream adjacent columns).
+template <typename R, int N, bool REG, bool SPLIT, bool GRAD, bool STATES, int FLAGS = 7>
 __global__ void __launch_bounds__(SPLIT ? 192 : 64)
 rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
                const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost, R* __restrict__ gradT,
                R* __restrict__ Pout, R* __restrict__ Vout, unsigned long long* __restrict__ key, uint32_t index_base) {
+  {
+    const size_t bi = blockIdx.y, ss = (size_t)3 * ld, st = (size_t)3 * q.N * ld;
+    p0 += bi * ss; v0 += bi * ss; T += bi * st; cost += bi * (size_t)ld;
+    if (goal != nullptr) goal += bi * ss;
+    if (GRAD) gradT += bi * st;
+    if (STATES) { Pout += bi * st; Vout += bi * st; }
+    if (key != nullptr) key += bi;
+  }
+  int blk = blockIdx.x;
+  if ((FLAGS & 4) && (gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
   const int lane = threadIdx.x & (kWave - 1);
-  const int b0 = blockIdx.x * kWave + lane;
+  const int b0 = blk * kWave + lane;
   const bool live = b0 < B;
   const int b = live ? b0 : B - 1;          // tail lanes shadow the last trajectory: identical loads, identical
                                             // (benign duplicate) stores, no contribution to cost/key
@@ -447,8 +465,8 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
     __shared__ R part[3][kWave];
     const int a = wave_uniform((int)(threadIdx.x / kWave));   // wave index -> SGPR, so row bases stay scalar
     R c;
-    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
-    else c = rollout_axis_rev<R, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, STATES, (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+    else c = rollout_axis_rev<R, GRAD, STATES, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
     part[a][lane] = c;
     __syncthreads();
     total = part[0][lane] + part[1][lane] + part[2][lane];
@@ -457,8 +475,8 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
     total = (R)0;
 #pragma unroll 1
     for (int a = 0; a < 3; ++a) {
-      if constexpr (REG) total += rollout_axis_reg<R, N, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
-      else total += rollout_axis_rev<R, GRAD, STATES>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+      if constexpr (REG) total += rollout_axis_reg<R, N, GRAD, STATES, (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+      else total += rollout_axis_rev<R, GRAD, STATES, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
     }
     rollout_epilogue<R>(live, b, total, cost, key, index_base);
   }
@@ -682,22 +700,24 @@ int extract_impl(const se3mpc_params* p, int B, int ld, const R* T, R* acc, R* a
   return launch_status("se3mpc_extract");
 }
 
-static int g_rollout_variant = 0;   // 0 auto, 1 REG split, 2 LDS, 3 REV split, 4 REG mono, 5 REV mono
+static int g_rollout_variant = 0;   // 0 auto, 1 REG split, 2 LDS, 3 REV split, 4 REG mono, 5 REV mono; +8*(FLAGS+1): explicit FLAGS (N = 30 f32 grad only)
 
 template <typename R, bool GRAD, bool STATES>
 int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* p0, const R* v0, const R* goal,
                    const R* T, R* cost, R* gradT, R* P, R* V, unsigned long long* key, uint32_t index_base,
-                   hipStream_t s) {
+                   int nbatch, hipStream_t s) {
   const DevParams<R> q = make_dev_params<R>(*p);
   const int nblk = grid_for(B, kWave);
+  const int flags = variant >> 3;
+  variant &= 7;
   const int N = p->horizon;
   // exact-N register kernels exist for the BASELINE horizons; f64 arrays spill beyond N = 20
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
   if (variant == 0) variant = has_reg ? 1 : 3;
   if ((variant == 1 || variant == 4) && !has_reg) variant = (variant == 1) ? 3 : 5;
 #define SE3MPC_LAUNCH(NN, REG, SPLIT)                                                                               \
-  hipLaunchKernelGGL((rollout_kernel<R, NN, REG, SPLIT, GRAD, STATES>), dim3(nblk), dim3(SPLIT ? 192 : 64), 0, s, q,  \
-                     B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base)
+  hipLaunchKernelGGL((rollout_kernel<R, NN, REG, SPLIT, GRAD, STATES>), dim3(nblk, nbatch), dim3(SPLIT ? 192 : 64), 0, \
+                     s, q, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base)
 #define SE3MPC_REG_SWITCH(SPLIT)                                                                                    \
   switch (N) {                                                                                                      \
     case 6: SE3MPC_LAUNCH(6, true, SPLIT); break;                                                                   \
@@ -708,12 +728,29 @@ int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* 
         else SE3MPC_LAUNCH(50, true, SPLIT);                                                                        \
       }                                                                                                             \
   }
+  if constexpr (sizeof(R) == 4 && GRAD && !STATES) {
+    if (variant == 1 && N == 30 && flags != 0) {      // tuning A/B on the benchmarked instantiation: FLAGS = flags - 1
+#define SE3MPC_FLAG_CASE(F)                                                                                         \
+  case F:                                                                                                           \
+    hipLaunchKernelGGL((rollout_kernel<R, 30, true, true, GRAD, STATES, F>), dim3(nblk, nbatch), dim3(192), 0, s, q,  \
+                       B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base);                                 \
+    break;
+      switch (flags - 1) {
+        SE3MPC_FLAG_CASE(0) SE3MPC_FLAG_CASE(1) SE3MPC_FLAG_CASE(2) SE3MPC_FLAG_CASE(3) SE3MPC_FLAG_CASE(4)
+        SE3MPC_FLAG_CASE(5) SE3MPC_FLAG_CASE(6)
+        default: SE3MPC_FLAG_CASE(7)
+      }
+#undef SE3MPC_FLAG_CASE
+      return launch_status("se3mpc_rollout_cost_grad");
+    }
+  }
   if (variant == 1) { SE3MPC_REG_SWITCH(true) }
   else if (variant == 4) { SE3MPC_REG_SWITCH(false) }
   else if (variant == 3) SE3MPC_LAUNCH(0, false, true);
   else if (variant == 5) SE3MPC_LAUNCH(0, false, false);
   else {
     const size_t lds = (size_t)2 * N * kWave * sizeof(R);
+    if (nbatch != 1) return SE3MPC_ERR_SHAPE;         // the LDS variant is single-batch (measurement only)
     hipLaunchKernelGGL((rollout_lds_kernel<R, GRAD, STATES>), dim3(nblk), dim3(kWave), lds, s, q, B, ld, p0, v0, goal,
                        T, cost, gradT, P, V, key, index_base);
   }
@@ -724,8 +761,10 @@ int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* 
 
 template <typename R>
 int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal, const R* T,
-                           R* cost, R* gradT, R* P, R* V, uint64_t* key64, uint32_t index_base, void* stream) {
+                           R* cost, R* gradT, R* P, R* V, uint64_t* key64, uint32_t index_base, int nbatch,
+                           void* stream) {
   unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
+  if (nbatch < 1 || nbatch > 65535) return SE3MPC_ERR_SHAPE;
   int rc = check_lane_args(p, B, ld);
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
@@ -735,10 +774,10 @@ int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   hipStream_t s = (hipStream_t)stream;
   const int var = g_rollout_variant;
   const bool grad = gradT != nullptr, states = P != nullptr;
-  if (grad && states) return rollout_launch<R, true, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
-  if (grad) return rollout_launch<R, true, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
-  if (states) return rollout_launch<R, false, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
-  return rollout_launch<R, false, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, s);
+  if (grad && states) return rollout_launch<R, true, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, nbatch, s);
+  if (grad) return rollout_launch<R, true, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, nbatch, s);
+  if (states) return rollout_launch<R, false, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, nbatch, s);
+  return rollout_launch<R, false, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, nbatch, s);
 }
 
 template <typename R>
@@ -811,7 +850,13 @@ using namespace se3mpc;
   extern "C" int se3mpc_rollout_cost_grad_##SUF(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0,          \
                                                 const R* goal, const R* T, R* cost, R* gradT, R* P, R* V,                \
                                                 uint64_t* key, uint32_t index_base, void* stream) {                      \
-    return rollout_cost_grad_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, stream);             \
+    return rollout_cost_grad_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, 1, stream);          \
+  }                                                                                                                      \
+  extern "C" int se3mpc_rollout_cost_grad_batched_##SUF(const se3mpc_params* p, int B, int ld, int nbatch, const R* p0,   \
+                                                        const R* v0, const R* goal, const R* T, R* cost, R* gradT,       \
+                                                        uint64_t* keys, uint32_t index_base, void* stream) {             \
+    return rollout_cost_grad_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, (R*)nullptr, (R*)nullptr, keys, index_base, \
+                                     nbatch, stream);                                                                    \
   }                                                                                                                      \
   extern "C" int se3mpc_is_plan_valid_##SUF(const se3mpc_params* p, int B, int ld, const R* P, const R* V,                \
                                             int32_t* valid, void* stream) {                                              \
@@ -825,7 +870,7 @@ using namespace se3mpc;
   }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant > 5) return SE3MPC_ERR_SHAPE;
+  if (variant < 0 || variant > 71 || (variant & 7) > 5) return SE3MPC_ERR_SHAPE;
   se3mpc::g_rollout_variant = variant;
   return SE3MPC_OK;
 }

@@ -122,18 +122,23 @@ __device__ __forceinline__ LaneBuf<R> lane_buf(const R* base) {
   b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<R*>(base), 0, 0xFFFFFFFF, 0x00020000);
   return b;
 }
+// AUX: cache-policy bits of the buffer instruction (0 = default, 2 = nt: streamed once, do not keep).
+template <int AUX = 0>
 __device__ __forceinline__ float lane_ld(const LaneBuf<float>& b, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rsrc, voff, soff, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rsrc, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ double lane_ld(const LaneBuf<double>& b, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, voff, soff, 0));
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, voff, soff, AUX));
 }
+template <int AUX = 0>
 __device__ __forceinline__ void lane_st(const LaneBuf<float>& b, unsigned voff, unsigned soff, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.rsrc, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), b.rsrc, voff, soff, AUX);
 }
+template <int AUX = 0>
 __device__ __forceinline__ void lane_st(const LaneBuf<double>& b, unsigned voff, unsigned soff, double v) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b.rsrc, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b.rsrc, voff, soff, AUX);
 }
 
 // Tell the compiler a value is the same in every lane (moves it to an SGPR).

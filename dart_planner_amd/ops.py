@@ -198,6 +198,25 @@ class Ops:
                       self.be.stream(), params=params)
         return cost, gradT, P, V
 
+    def rollout_cost_grad_batched(self, params: Params, p0, v0, goal, T, cost, gradT, keys=None, index_base: int = 0):
+        """`nbatch` independent batches in one launch.  p0, v0, goal: (nbatch, 3, ld); T, gradT:
+        (nbatch, 3N, ld); cost: (nbatch, ld); keys: int64 (nbatch,) preset to -1, or None.  Outputs are
+        caller-allocated (steady-state use)."""
+        N = params.horizon
+        nb, _, ld = T.shape
+        for a, shp, nm in ((p0, (nb, 3, ld), "p0"), (v0, (nb, 3, ld), "v0"), (T, (nb, 3 * N, ld), "T"),
+                           (cost, (nb, ld), "cost"), (gradT, (nb, 3 * N, ld), "gradT")):
+            self.be.check(a, nm)
+            if tuple(a.shape) != shp:
+                raise ValueError(f"{nm}: expected {shp}, got {tuple(a.shape)}")
+        if params.has_goal:
+            self.be.check(goal, "goal")
+        suf = self.be.suffix(T)
+        self.lib.call("rollout_cost_grad_batched", suf, ld, ld, nb, self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost),
+                      self.be.ptr(gradT), self.be.ptr(keys), int(index_base), self.be.stream(), params=params)
+        return cost, gradT
+
     def is_plan_valid(self, params: Params, P, V=None, B: Optional[int] = None):
         """a16: -> int32 (ld,)."""
         N = params.horizon

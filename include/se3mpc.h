@@ -175,10 +175,25 @@ int se3mpc_rollout_cost_grad_f64(const se3mpc_params* p, int B, int ld, const do
                                  const double* goal, const double* T, double* cost, double* gradT, double* P,
                                  double* V, uint64_t* key, uint32_t index_base, void* stream);
 
+/* Multi-batch launch of the same kernel: `nbatch` independent batches in ONE launch (grid.y), laid out as
+ * consecutive blocks -- p0, v0, goal: [nbatch][3][ld]; T, gradT: [nbatch][3N][ld]; cost: [nbatch][ld];
+ * keys: [nbatch] (NULL or preset to UINT64_MAX).  For callers that hold many independent sample
+ * batches (Monte-Carlo sweeps, several planners): one launch amortises the launch latency that
+ * dominates a single 8192-rollout batch.  1 <= nbatch <= 65535. */
+int se3mpc_rollout_cost_grad_batched_f32(const se3mpc_params* p, int B, int ld, int nbatch, const float* p0,
+                                         const float* v0, const float* goal, const float* T, float* cost,
+                                         float* gradT, uint64_t* keys, uint32_t index_base, void* stream);
+int se3mpc_rollout_cost_grad_batched_f64(const se3mpc_params* p, int B, int ld, int nbatch, const double* p0,
+                                         const double* v0, const double* goal, const double* T, double* cost,
+                                         double* gradT, uint64_t* keys, uint32_t index_base, void* stream);
+
 /* Tuning knob for measurements: which implementation of the rollout the entry point above
  * launches.  0 = auto (default), 1 = exact-N register arrays (N in {6,20,30,50}; falls back to
- * 2 otherwise), 2 = per-step state tiles staged in LDS, 3 = register-light reversible sweep.
- * All three compute the same quantities. */
+ * 3 otherwise), 2 = per-step state tiles staged in LDS, 3 = register-light reversible sweep, 4 / 5 = 1 / 3
+ * with one wavefront looping over the three axes.  variant + 8 * (flags + 1) forces the memory-policy
+ * flags of the benchmarked instantiation (horizon 30, f32, gradient): bit 0 nt loads, bit 1 nt stores,
+ * bit 2 XCD-contiguous block order; the default is all three (7).  All compute the same quantities
+ * (DESIGN.md section 5). */
 int se3mpc_set_rollout_variant(int variant);
 
 /* Replaces is_plan_valid (planner.py:717-737): valid[b] = 1 iff all positions finite,

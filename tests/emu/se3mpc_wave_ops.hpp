@@ -37,11 +37,11 @@ template <typename R>
 struct LaneBuf { const char* base; };
 template <typename R>
 inline LaneBuf<R> lane_buf(const R* base) { return LaneBuf<R>{reinterpret_cast<const char*>(base)}; }
-template <typename R>
+template <int AUX = 0, typename R>
 inline R lane_ld(const LaneBuf<R>& b, unsigned voff, unsigned soff) {
   return *reinterpret_cast<const R*>(b.base + (size_t)soff + voff);
 }
-template <typename R>
+template <int AUX = 0, typename R>
 inline void lane_st(const LaneBuf<R>& b, unsigned voff, unsigned soff, R v) {
   *reinterpret_cast<R*>(const_cast<char*>(b.base) + (size_t)soff + voff) = v;
 }

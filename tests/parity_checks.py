@@ -135,6 +135,20 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
             assert g_none is None and np.allclose(h.to_host(c_only), h.to_host(cost), rtol=t["cost_rel"], atol=0)
         finally:
             h.ops.lib.set_rollout_variant(0)
+    # multi-batch launch == the same batches launched one by one (incl. per-batch keys)
+    nb = 3
+    rngb = np.random.default_rng(seed + 100)
+    bp0, bv0, bgoal, bT = (np.stack(x) for x in zip(*[random_batch(rngb, B, N) for _ in range(nb)]))
+    st = lambda a, rows: h.to_dev(np.ascontiguousarray(np.transpose(a.reshape(nb, B, rows), (0, 2, 1)).astype(h.dt)))
+    dp0, dv0, dgoal, dT = st(bp0, 3), st(bv0, 3), st(bgoal, 3), st(bT, 3 * N)
+    costb = h.to_dev(np.zeros((nb, B), dtype=h.dt)); gradb = h.to_dev(np.zeros((nb, 3 * N, B), dtype=h.dt))
+    keysb = h.to_dev(np.full(nb, -1, dtype=np.int64))
+    h.ops.rollout_cost_grad_batched(prm, dp0, dv0, dgoal, dT, costb, gradb, keys=keysb, index_base=11)
+    for i in range(nb):
+        ci, gi, _, _ = h.ops.rollout_cost_grad(prm, h.lane(bp0[i], B), h.lane(bv0[i], B), h.lane(bgoal[i], B), h.lane(bT[i], B))
+        assert np.array_equal(h.to_host(costb)[i], h.to_host(ci)) and np.array_equal(h.to_host(gradb)[i], h.to_host(gi))
+        ki = int(h.to_host(keysb)[i]) & 0xFFFFFFFFFFFFFFFF
+        assert h.ops.lib.key_index(ki) == 11 + int(np.argmin(h.to_host(ci)))
     # the rolled-out states satisfy the reference's dynamics constraints (a8 == 0)
     Xr = orc.pack(P_ref, V_ref, T)
     Rr = h.ops.dynamics_residual(prm, h.lane(Xr, B), h.lane(p0, B), h.lane(v0, B))
