@@ -169,40 +169,44 @@ def main():
     ring = a.ring if a.ring > 0 else max(2, math.ceil(512 * 2 ** 20 / slot_bytes))
     ring = S * max(2, math.ceil(ring / S))                     # whole launches, consecutive launches on disjoint slots
     p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=3 + rank)
-    keys = torch.full((max(K, 1),), -1, dtype=torch.int64, device=dev)        # UINT64_MAX
-    wkeys = torch.full((max(W, S),), -1, dtype=torch.int64, device=dev)
+    per = (B + 63) // 64                                        # wave-key slots per batch
+    wave_keys = torch.zeros(max(K, W, S), per, dtype=torch.int64, device=dev)
+    keys = torch.full((max(K, 1),), -1, dtype=torch.int64, device=dev)
     base = rank * B
 
-    def launch(i0, n, kbuf):
-        """steps i0 .. i0+n-1 (n <= S consecutive ring slots) as ONE launch"""
+    def launch(i0, n):
+        """steps i0 .. i0+n-1 (n <= S consecutive ring slots) as ONE launch; step i's wavefronts write
+        their partial argmin keys to wave_keys[i]"""
         s0 = i0 % ring
         if n == 1:
-            ops.rollout_cost_grad(prm, p0[s0], v0[s0], goal[s0], T[s0], out=(cost[s0], grad[s0]), key=kbuf[i0:i0 + 1], index_base=base)
+            ops.rollout_cost_grad(prm, p0[s0], v0[s0], goal[s0], T[s0], out=(cost[s0], grad[s0]), wave_keys=wave_keys[i0], index_base=base)
         else:
             ops.rollout_cost_grad_batched(prm, p0[s0:s0 + n], v0[s0:s0 + n], goal[s0:s0 + n], T[s0:s0 + n], cost[s0:s0 + n],
-                                          grad[s0:s0 + n], keys=kbuf[i0:i0 + n], index_base=base)
+                                          grad[s0:s0 + n], wave_keys=wave_keys[i0:i0 + n], index_base=base)
 
-    def run_steps(nsteps, per_launch, kbuf):
+    def run_steps(nsteps, per_launch, fold=True):
         i = 0
         while i < nsteps:
             n = min(per_launch, nsteps - i)
             n = min(n, ring - (i % ring))
-            launch(i, n, kbuf)
+            launch(i, n)
             i += n
+        if fold:                                                # one bucketed fold of all steps' wave keys -> keys[step]
+            ops.reduce_keys(wave_keys[:nsteps], keys[:nsteps])
 
     results = {}
-    for mode, per in (("primary", S), ("single_launch", 1)):
+    for mode, per_l in (("primary", S), ("single_launch", 1)):
         if mode == "single_launch" and (S == 1 or a.no_single):
             continue
-        run_steps(W, per, wkeys)                                # untimed warm-up (eager)
+        run_steps(W, per_l, fold=False)                         # untimed warm-up (eager)
         torch.cuda.synchronize()
-        graph = None if a.no_graph else capture(torch, dev, lambda: run_steps(K, per, keys))
+        graph = None if a.no_graph else capture(torch, dev, lambda: run_steps(K, per_l))
         keys.fill_(-1)
         torch.cuda.synchronize()
-        elapsed, dev_ms = timed_region(torch, dist, world, dev, K, lambda: run_steps(K, per, keys), graph, keys, allreduce_min_keys)
-        nlaunch = sum(1 for _ in _launch_sizes(K, per, ring))
+        elapsed, dev_ms = timed_region(torch, dist, world, dev, K, lambda: run_steps(K, per_l), graph, keys, allreduce_min_keys)
+        nlaunch = sum(1 for _ in _launch_sizes(K, per_l, ring))
         kh = keys[:K].cpu().numpy().view(np.uint64)
-        results[mode] = dict(elapsed=elapsed, launch_ms=dev_ms / nlaunch, nlaunch=nlaunch, per=per, graph=graph is not None,
+        results[mode] = dict(elapsed=elapsed, launch_ms=dev_ms / nlaunch, nlaunch=nlaunch, per=per_l, graph=graph is not None,
                              keys_valid=bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B))))
         del graph
 

@@ -173,12 +173,14 @@ class Ops:
         return acc, att, rates, thrust
 
     def rollout_cost_grad(self, params: Params, p0, v0, goal, T, want_grad: bool = True, want_states: bool = False,
-                          B: Optional[int] = None, out=None, key=None, index_base: int = 0):
+                          B: Optional[int] = None, out=None, key=None, index_base: int = 0, wave_keys=None):
         """Shooting-form rollout + cost (+ gradient wrt T, + rolled-out states).
         -> (cost (ld,), gradT (3N, ld) | None, P (3N, ld) | None, V (3N, ld) | None).
         ``out=(cost, gradT)`` reuses preallocated outputs (the benchmark's steady state).
-        ``key`` (int64 (1,), preset to -1 == UINT64_MAX by the caller) receives the fused batch
-        argmin: min over b of (orderable cost bits << 32 | index_base + b)."""
+        ``key`` (int64 (1,)) receives the fused batch argmin: min over b of (orderable cost bits << 32 |
+        index_base + b) -- the kernel writes one partial key per wavefront (``wave_keys``, int64
+        (ceil(ld/64),), allocated here unless given) and se3mpc_reduce_keys folds them.  Pass
+        ``wave_keys`` alone to defer the fold (bucketed use, see bench.py)."""
         N = params.horizon
         self._lane(p0, 3, "p0"); self._lane(v0, 3, "v0"); self._lane(T, 3 * N, "T")
         if params.has_goal:
@@ -192,16 +194,27 @@ class Ops:
             gradT = self.be.empty((3 * N, ld), suf) if want_grad else None
         P = self.be.empty((3 * N, ld), suf) if want_states else None
         V = self.be.empty((3 * N, ld), suf) if want_states else None
-        self.lib.call("rollout_cost_grad", suf, self._B(ld, B), ld, self.be.ptr(p0), self.be.ptr(v0),
+        nB = self._B(ld, B)
+        if key is not None and wave_keys is None:
+            wave_keys = self.be.empty(((nB + 63) // 64,), "i64")
+        self.lib.call("rollout_cost_grad", suf, nB, ld, self.be.ptr(p0), self.be.ptr(v0),
                       self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost),
-                      self.be.ptr(gradT), self.be.ptr(P), self.be.ptr(V), self.be.ptr(key), int(index_base),
+                      self.be.ptr(gradT), self.be.ptr(P), self.be.ptr(V), self.be.ptr(wave_keys), int(index_base),
                       self.be.stream(), params=params)
+        if key is not None and nB > 0:
+            self.lib.reduce_keys(self.be.ptr(wave_keys), (nB + 63) // 64, 1, self.be.ptr(key), self.be.stream())
         return cost, gradT, P, V
 
-    def rollout_cost_grad_batched(self, params: Params, p0, v0, goal, T, cost, gradT, keys=None, index_base: int = 0):
+    def reduce_keys(self, wave_keys, keys_out):
+        """wave_keys int64 (nbatch, per_batch) -> keys_out int64 (nbatch,)."""
+        nb, per = wave_keys.shape
+        self.lib.reduce_keys(self.be.ptr(wave_keys), per, nb, self.be.ptr(keys_out), self.be.stream())
+        return keys_out
+
+    def rollout_cost_grad_batched(self, params: Params, p0, v0, goal, T, cost, gradT, wave_keys=None, index_base: int = 0):
         """`nbatch` independent batches in one launch.  p0, v0, goal: (nbatch, 3, ld); T, gradT:
-        (nbatch, 3N, ld); cost: (nbatch, ld); keys: int64 (nbatch,) preset to -1, or None.  Outputs are
-        caller-allocated (steady-state use)."""
+        (nbatch, 3N, ld); cost: (nbatch, ld); wave_keys: int64 (nbatch, ceil(ld/64)) or None (fold with
+        :meth:`reduce_keys`).  Outputs are caller-allocated (steady-state use)."""
         N = params.horizon
         nb, _, ld = T.shape
         for a, shp, nm in ((p0, (nb, 3, ld), "p0"), (v0, (nb, 3, ld), "v0"), (T, (nb, 3 * N, ld), "T"),
@@ -214,7 +227,7 @@ class Ops:
         suf = self.be.suffix(T)
         self.lib.call("rollout_cost_grad_batched", suf, ld, ld, nb, self.be.ptr(p0), self.be.ptr(v0),
                       self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost),
-                      self.be.ptr(gradT), self.be.ptr(keys), int(index_base), self.be.stream(), params=params)
+                      self.be.ptr(gradT), self.be.ptr(wave_keys), int(index_base), self.be.stream(), params=params)
         return cost, gradT
 
     def is_plan_valid(self, params: Params, P, V=None, B: Optional[int] = None):

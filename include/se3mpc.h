@@ -165,27 +165,31 @@ int se3mpc_extract_f64(const se3mpc_params* p, int B, int ld, const double* T, d
  * recurrence that planner.py:449-460 writes as residuals, the objective of planner.py:516-550
  * on the rolled-out states, and its exact gradient wrt the thrust sequence by the reverse
  * sweep.  cost: [B]; gradT: [3N][ld] or NULL; P, V: [3N][ld] or both NULL (rolled-out states).
- * key: NULL, or a device word the kernel folds the batch argmin into (fused form of
- * se3mpc_argmin_*: *key = min(*key, orderable(cost[b]) << 32 | (index_base + b)), one 64-bit
- * atomic per wavefront); the CALLER presets *key to UINT64_MAX (memset 0xFF). */
+ * wave_keys: NULL, or [ceil(B/64)] device words: the kernel WRITES slot w = min over trajectories
+ * 64w..64w+63 of (orderable(cost[b]) << 32 | (index_base + b)) -- the batch argmin fused into the
+ * rollout, one plain store per wavefront, no atomics, no pre-initialisation; se3mpc_reduce_keys folds
+ * the slots into one key per batch (same packed key as se3mpc_argmin_*). */
 int se3mpc_rollout_cost_grad_f32(const se3mpc_params* p, int B, int ld, const float* p0, const float* v0,
                                  const float* goal, const float* T, float* cost, float* gradT, float* P,
-                                 float* V, uint64_t* key, uint32_t index_base, void* stream);
+                                 float* V, uint64_t* wave_keys, uint32_t index_base, void* stream);
 int se3mpc_rollout_cost_grad_f64(const se3mpc_params* p, int B, int ld, const double* p0, const double* v0,
                                  const double* goal, const double* T, double* cost, double* gradT, double* P,
-                                 double* V, uint64_t* key, uint32_t index_base, void* stream);
+                                 double* V, uint64_t* wave_keys, uint32_t index_base, void* stream);
 
 /* Multi-batch launch of the same kernel: `nbatch` independent batches in ONE launch (grid.y), laid out as
  * consecutive blocks -- p0, v0, goal: [nbatch][3][ld]; T, gradT: [nbatch][3N][ld]; cost: [nbatch][ld];
- * keys: [nbatch] (NULL or preset to UINT64_MAX).  For callers that hold many independent sample
+ * wave_keys: NULL or [nbatch][ceil(B/64)].  For callers that hold many independent sample
  * batches (Monte-Carlo sweeps, several planners): one launch amortises the launch latency that
  * dominates a single 8192-rollout batch.  1 <= nbatch <= 65535. */
 int se3mpc_rollout_cost_grad_batched_f32(const se3mpc_params* p, int B, int ld, int nbatch, const float* p0,
                                          const float* v0, const float* goal, const float* T, float* cost,
-                                         float* gradT, uint64_t* keys, uint32_t index_base, void* stream);
+                                         float* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream);
 int se3mpc_rollout_cost_grad_batched_f64(const se3mpc_params* p, int B, int ld, int nbatch, const double* p0,
                                          const double* v0, const double* goal, const double* T, double* cost,
-                                         double* gradT, uint64_t* keys, uint32_t index_base, void* stream);
+                                         double* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream);
+
+/* keys_out[i] = min over wave_keys[i][0..per_batch) for i < nbatch (one small workgroup per batch). */
+int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uint64_t* keys_out, void* stream);
 
 /* Tuning knob for measurements: which implementation of the rollout the entry point above
  * launches.  0 = auto (default), 1 = exact-N register arrays (N in {6,20,30,50}; falls back to

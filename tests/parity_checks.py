@@ -142,8 +142,10 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
     st = lambda a, rows: h.to_dev(np.ascontiguousarray(np.transpose(a.reshape(nb, B, rows), (0, 2, 1)).astype(h.dt)))
     dp0, dv0, dgoal, dT = st(bp0, 3), st(bv0, 3), st(bgoal, 3), st(bT, 3 * N)
     costb = h.to_dev(np.zeros((nb, B), dtype=h.dt)); gradb = h.to_dev(np.zeros((nb, 3 * N, B), dtype=h.dt))
-    keysb = h.to_dev(np.full(nb, -1, dtype=np.int64))
-    h.ops.rollout_cost_grad_batched(prm, dp0, dv0, dgoal, dT, costb, gradb, keys=keysb, index_base=11)
+    wkb = h.to_dev(np.zeros((nb, (B + 63) // 64), dtype=np.int64))
+    keysb = h.to_dev(np.zeros(nb, dtype=np.int64))
+    h.ops.rollout_cost_grad_batched(prm, dp0, dv0, dgoal, dT, costb, gradb, wave_keys=wkb, index_base=11)
+    h.ops.reduce_keys(wkb, keysb)
     for i in range(nb):
         ci, gi, _, _ = h.ops.rollout_cost_grad(prm, h.lane(bp0[i], B), h.lane(bv0[i], B), h.lane(bgoal[i], B), h.lane(bT[i], B))
         assert np.array_equal(h.to_host(costb)[i], h.to_host(ci)) and np.array_equal(h.to_host(gradb)[i], h.to_host(gi))

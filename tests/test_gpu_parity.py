@@ -92,7 +92,7 @@ def test_full_size_rollout_properties(gpu_ops):
         goal = torch.rand(3, B, device=dev, generator=g) * 40 - 20
         T = torch.randn(3 * N, B, device=dev, generator=g) * 2
         T[2::3] += 14.715
-        key = torch.full((1,), -1, dtype=torch.int64, device=dev)
+        key = torch.zeros(1, dtype=torch.int64, device=dev)
         cost, gT, P, V = ops.rollout_cost_grad(prm, p0, v0, goal, T, want_states=True, key=key)
         X = torch.cat([P, V, T], dim=0).contiguous()
         R = ops.dynamics_residual(prm, X, p0, v0)

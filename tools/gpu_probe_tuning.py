@@ -13,7 +13,7 @@ def mk(nb, B):
     p0 = torch.rand(nb, 3, B, device=dev, generator=g) * 40 - 20; v0 = torch.rand(nb, 3, B, device=dev, generator=g) * 10 - 5
     goal = torch.rand(nb, 3, B, device=dev, generator=g) * 40 - 20
     T = torch.randn(nb, 3 * N, B, device=dev, generator=g) * 2; T[:, 2::3] += 14.715
-    return p0, v0, goal, T, torch.empty(nb, B, device=dev), torch.empty(nb, 3 * N, B, device=dev), torch.full((nb,), -1, dtype=torch.int64, device=dev)
+    return p0, v0, goal, T, torch.empty(nb, B, device=dev), torch.empty(nb, 3 * N, B, device=dev), torch.zeros(nb, (B + 63) // 64, dtype=torch.int64, device=dev)
 for name, nb, B, reps in (("fused_87x8192", 87, 8192, 30), ("fused_348x8192", 348, 8192, 10), ("fused_1024x8192", 1024, 8192, 5), ("single_1M", 1, 1 << 20, 30), ("single_4M", 1, 1 << 22, 10)):
     bufs = mk(nb, B)
     times = {}
@@ -21,12 +21,12 @@ for name, nb, B, reps in (("fused_87x8192", 87, 8192, 30), ("fused_348x8192", 34
         for flags in range(8):
             lib.set_rollout_variant(1 + 8 * (flags + 1))
             p0, v0, goal, T, cost, grad, keys = bufs
-            ops.rollout_cost_grad_batched(prm, p0, v0, goal, T, cost, grad, keys=keys)
+            ops.rollout_cost_grad_batched(prm, p0, v0, goal, T, cost, grad, wave_keys=keys)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(reps):
-                ops.rollout_cost_grad_batched(prm, p0, v0, goal, T, cost, grad, keys=keys)
+                ops.rollout_cost_grad_batched(prm, p0, v0, goal, T, cost, grad, wave_keys=keys)
             e1.record(); torch.cuda.synchronize()
             times.setdefault(flags, []).append(e0.elapsed_time(e1) / reps)
     lib.set_rollout_variant(0)
