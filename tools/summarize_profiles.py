@@ -8,6 +8,7 @@ import sys
 import numpy as np
 
 root = sys.argv[1]
+N, B = 30, 8192
 
 
 def find(sub, pattern):
@@ -15,38 +16,53 @@ def find(sub, pattern):
     return f[0] if f else None
 
 
-def kernel_durations(sub, needle):
+def rows_of(sub, needle):
     f = find(sub, "*kernel_trace.csv")
-    if not f:
-        return None
-    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(f)) if needle in r["Kernel_Name"]]
+    return [] if not f else [r for r in csv.DictReader(open(f)) if needle in r["Kernel_Name"]]
+
+
+def durations(rows, grid_y=None):
+    d = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows if grid_y is None or int(r["Grid_Size_Y"]) == grid_y]
     if not d:
         return None
     d = np.array(d[len(d) // 10:], dtype=float)     # drop the warm-up tenth
     return dict(calls=int(len(d)), avg_ns=float(d.mean()), median_ns=float(np.median(d)), min_ns=float(d.min()), max_ns=float(d.max()))
 
 
-def counter(sub, needle, name):
+def counter(sub, needle, name, grid_y=None):
     f = find(sub, "*counter_collection.csv")
     if not f:
         return None
-    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if needle in r["Kernel_Name"] and r["Counter_Name"] == name]
+    vals = []
+    for r in csv.DictReader(open(f)):
+        if needle in r["Kernel_Name"] and r["Counter_Name"] == name:
+            vals.append(float(r["Counter_Value"]))
     if not vals:
         return None
-    vals = np.array(vals[len(vals) // 10:])
+    vals = np.array(vals)
+    if grid_y is not None:                # keep the dispatches of the dominant (largest) size
+        vals = vals[vals > 0.5 * vals.max()]
+    vals = vals[len(vals) // 10:]
     return dict(dispatches=int(len(vals)), mean=float(vals.mean()), median=float(np.median(vals)))
 
 
-out = {"rollout_b8192_graph": kernel_durations("trace", "rollout_kernel"), "solve_kernel": kernel_durations("solve", "solve_kernel")}
-N = 30
-for tag, B in (("b8192", 8192), ("b4m", 4194304)):
-    alg_r = 4 * (3 * N + 9) * B
-    alg_w = 4 * (3 * N + 1) * B
-    fe = counter(f"pmc_FETCH_SIZE_{tag}", "rollout_kernel", "FETCH_SIZE")
-    wr = counter(f"pmc_WRITE_SIZE_{tag}", "rollout_kernel", "WRITE_SIZE")
-    dur = kernel_durations(f"pmc_FETCH_SIZE_{tag}", "rollout_kernel")
-    out[f"pmc_{tag}"] = dict(batch=B, algorithmic_read_bytes=alg_r, algorithmic_write_bytes=alg_w, FETCH_SIZE_KB=fe, WRITE_SIZE_KB=wr,
-                            kernel_ns_under_pmc=dur,
+tr = rows_of("trace", "rollout_kernel")
+out = {"rollout_fused_64x8192_graph": durations(tr, 64), "rollout_single_8192_graph": durations(tr, 1),
+       "solve_kernel_single_problem": None, "solve_kernel_batch_8192": None}
+sv = rows_of("solve", "solve_kernel")
+if sv:
+    one = [r for r in sv if int(r["Grid_Size_X"]) == 64]
+    many = [r for r in sv if int(r["Grid_Size_X"]) == 64 * B]
+    out["solve_kernel_single_problem"] = durations(one)
+    out["solve_kernel_batch_8192"] = durations(many)
+for tag, rollouts, gy in (("fused", 64 * B, 64), ("single", B, None), ("b4m", 4194304, None)):
+    alg_r = 4 * (3 * N + 9) * rollouts
+    alg_w = 4 * (3 * N + 1) * rollouts
+    fe = counter(f"pmc_FETCH_SIZE_{tag}", "rollout_kernel", "FETCH_SIZE", gy)
+    wr = counter(f"pmc_WRITE_SIZE_{tag}", "rollout_kernel", "WRITE_SIZE", gy)
+    out[f"pmc_{tag}"] = dict(rollouts_per_launch=rollouts, algorithmic_read_bytes=alg_r, algorithmic_write_bytes=alg_w,
+                            FETCH_SIZE_KB=fe, WRITE_SIZE_KB=wr,
+                            kernel_ns_under_pmc=durations(rows_of(f"pmc_FETCH_SIZE_{tag}", "rollout_kernel"), gy),
                             fetch_bytes_raw=None if fe is None else fe["mean"] * 1024,
                             write_bytes_raw=None if wr is None else wr["mean"] * 1024)
 print(json.dumps(out, indent=1))
