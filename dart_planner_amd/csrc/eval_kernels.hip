@@ -62,22 +62,25 @@ __global__ void init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__
 // a5 + a6: objective (planner.py:516-550) and the reference's gradient (planner.py:552-580)
 // ------------------------------------------------------------------------------------------
 template <typename R>
-__global__ void cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R* __restrict__ goal,
-                                 R* __restrict__ f, R* __restrict__ g) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+__global__ void __launch_bounds__(64)
+cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R* __restrict__ goal,
+                 R* __restrict__ f, R* __restrict__ g) {
+  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;                          // tail lanes shadow the last column (benign duplicate stores)
+  const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
+  const LaneBuf<R> xb = lane_buf(X), gb = lane_buf(g);
   R sp = 0, sv = 0, sa = 0, st = 0, sterm = 0;
   for (int a = 0; a < 3; ++a) {
     const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
     const R grav = (a == 2) ? q.grav : (R)0;
     const R hov = (a == 2) ? q.hover : (R)0;
-#pragma unroll 4
+#pragma unroll 6
     for (int k = 0; k < N; ++k) {
-      const size_t rp = (size_t)(3 * k + a) * ld + b;
-      const size_t rv = (size_t)(N3 + 3 * k + a) * ld + b;
-      const size_t rt = (size_t)(2 * N3 + 3 * k + a) * ld + b;
-      const R x = X[rp], v = X[rv], t = X[rt];
+      const unsigned rp = (unsigned)(3 * k + a) * rowb, rv = (unsigned)(N3 + 3 * k + a) * rowb,
+                     rt = (unsigned)(2 * N3 + 3 * k + a) * rowb;
+      const R x = lane_ld<2>(xb, voff, rp), v = lane_ld<2>(xb, voff, rv), t = lane_ld<2>(xb, voff, rt);   // streamed once: nt
       const R e = x - gl;
       const R acc = t * q.inv_mass - grav;                  // planner.py:535-537
       const R dev = t - hov;                                // planner.py:542
@@ -87,15 +90,15 @@ __global__ void cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restr
       st += dev * dev;
       if (k == N - 1) sterm += e * e;                       // planner.py:546-548
       if (g != nullptr) {
-        g[rp] = q.has_goal ? (R)2 * q.wp * e : (R)0;        // planner.py:567-570 (no terminal x10)
-        g[rv] = (R)2 * q.wv * v;                            // planner.py:573-574
-        g[rt] = (R)2 * q.wT * t;                            // planner.py:577-578 (no hover offset, no accel term)
+        lane_st<2>(gb, voff, rp, q.has_goal ? (R)2 * q.wp * e : (R)0);   // planner.py:567-570 (no terminal x10)
+        lane_st<2>(gb, voff, rv, (R)2 * q.wv * v);                       // planner.py:573-574
+        lane_st<2>(gb, voff, rt, (R)2 * q.wT * t);                       // planner.py:577-578 (no hover offset, no accel term)
       }
     }
   }
   R cost = q.wv * sv + q.wa * sa + q.wT * st;
   if (q.has_goal) cost += q.wp * sp + q.term * q.wp * sterm;
-  f[b] = cost;
+  if (live) f[b] = cost;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -666,6 +669,7 @@ int cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* g
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || !f || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  if ((uint64_t)9 * p->horizon * (uint64_t)ld * sizeof(R) >= (1ull << 32)) return SE3MPC_ERR_SHAPE;   // 32-bit buffer offsets
   hipLaunchKernelGGL(cost_grad_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
                      make_dev_params<R>(*p), B, ld, X, goal, f, g);
   return launch_status("se3mpc_cost_grad");

@@ -294,6 +294,52 @@ class Ops:
                       self.be.ptr(rates), self.be.ptr(thrust), self.be.stream(), params=params)
         return dict(x=X, info=info, accelerations=acc, attitudes=att, body_rates=rates, thrusts=thrust)
 
+    def solve_packed(self, params: Params, inputs, x0=None, out=None):
+        """Latency-oriented form of :meth:`solve` for the planner: ONE device buffer in, ONE out.
+        inputs: (3, B, 3) = stacked (p0, v0, goal) [goal ignored when has_goal == 0];
+        out: uint8 buffer of :meth:`packed_size` bytes (allocated if None) laid out as
+        [X | acc | att | rates | thrust | info]; decode on the host with :meth:`unpack_solution`."""
+        N = params.horizon
+        self.be.check(inputs, "inputs")
+        if inputs.ndim != 3 or inputs.shape[0] != 3 or inputs.shape[2] != 3:
+            raise ValueError(f"inputs: expected (3, B, 3), got {tuple(inputs.shape)}")
+        suf = self.be.suffix(inputs)
+        B = inputs.shape[1]
+        esz = 4 if suf == "f32" else 8
+        if out is None:
+            out = self.be.empty((self.packed_size(B, N, suf),), "u8")
+        base = self.be.ptr(out)
+        o_x, o_acc, o_att, o_rates, o_thr, o_info, _ = self._packed_offsets(B, N, esz)
+        step = B * 3 * esz
+        pin = self.be.ptr(inputs)
+        self.lib.call("solve", suf, B, pin, pin + step, (pin + 2 * step) if params.has_goal else 0, self.be.ptr(x0),
+                      base + o_x, base + o_info, base + o_acc, base + o_att, base + o_rates, base + o_thr,
+                      self.be.stream(), params=params)
+        return out
+
+    @staticmethod
+    def _packed_offsets(B, N, esz):
+        o_x = 0
+        o_acc = o_x + B * 9 * N * esz
+        o_att = o_acc + B * 3 * N * esz
+        o_rates = o_att + B * 3 * N * esz
+        o_thr = o_rates + B * 3 * N * esz
+        o_info = (o_thr + B * N * esz + 7) // 8 * 8
+        return o_x, o_acc, o_att, o_rates, o_thr, o_info, o_info + B * INFO_DTYPE.itemsize
+
+    def packed_size(self, B, N, suffix) -> int:
+        return self._packed_offsets(B, N, 4 if suffix == "f32" else 8)[-1]
+
+    def unpack_solution(self, host_bytes: np.ndarray, B: int, N: int, suffix: str):
+        """Host-side views into a packed result (no copies except the float64 cast for f32)."""
+        esz, dt = (4, np.float32) if suffix == "f32" else (8, np.float64)
+        o_x, o_acc, o_att, o_rates, o_thr, o_info, end = self._packed_offsets(B, N, esz)
+        raw = host_bytes
+        f = lambda lo, cnt, shape: np.frombuffer(raw, dtype=dt, count=cnt, offset=lo).reshape(shape).astype(np.float64)
+        return dict(x=f(o_x, B * 9 * N, (B, 9 * N)), accelerations=f(o_acc, B * 3 * N, (B, N, 3)),
+                    attitudes=f(o_att, B * 3 * N, (B, N, 3)), body_rates=f(o_rates, B * 3 * N, (B, N, 3)),
+                    thrusts=f(o_thr, B * N, (B, N)), info=np.frombuffer(raw, dtype=INFO_DTYPE, count=B, offset=o_info))
+
     def info_to_host(self, info) -> np.ndarray:
         """Device bytes of se3mpc_solve_info[B] -> NumPy structured array (synchronises)."""
         return np.frombuffer(self.be.to_host(info).tobytes(), dtype=INFO_DTYPE)

@@ -65,7 +65,8 @@ class SE3MPCConfig:
 class SE3MPCPlanner(BasePlanner):
     """planner.py:82-757."""
 
-    def __init__(self, config: Optional[SE3MPCConfig] = None, *, precision: str = "f64", device=None) -> None:
+    def __init__(self, config: Optional[SE3MPCConfig] = None, *, precision: str = "f64", device=None,
+                 receding_horizon: bool = False) -> None:
         if config is None:
             config = SE3MPCConfig()
         elif isinstance(config, dict):      # PlannerFactory.create hands over a dict (base_planner.py:131)
@@ -81,8 +82,13 @@ class SE3MPCPlanner(BasePlanner):
         self.hover_thrust = self.mass * self.gravity
         self.goal_position: Optional[np.ndarray] = None
         self.obstacles: List[Tuple[np.ndarray, float]] = []
-        self.last_solution: Optional[Dict[str, np.ndarray]] = None               # never assigned, as in the reference
+        # planner.py:158-159.  The reference never assigns last_solution, so its warm start
+        # (_create_warm_start, :294-327) is dead code and every solve is a cold start.  With
+        # receding_horizon=True this planner does what that code intended: it keeps the last solution
+        # and hands the shifted plan to the solver as x0.  Default: off = reference behaviour.
+        self.last_solution: Optional[Dict[str, np.ndarray]] = None
         self.warm_start_enabled = True
+        self.receding_horizon = bool(receding_horizon)
         self.planning_times: List[float] = []
         self.plan_count = 0
         self.convergence_history: List[bool] = []
@@ -157,7 +163,10 @@ class SE3MPCPlanner(BasePlanner):
         p0 = np.asarray(to_float(current_state.position), dtype=float).reshape(1, 3)
         v0 = np.asarray(to_float(current_state.velocity), dtype=float).reshape(1, 3)
         goal = None if self.goal_position is None else np.asarray(self.goal_position, float).reshape(1, 3)
-        res = self._solve_batch(p0, v0, goal, None, self.precision)
+        x0 = None
+        if self.warm_start_enabled and self.last_solution is not None:          # planner.py:287-289
+            x0 = self._create_warm_start(current_state, self.se3_config.prediction_horizon).reshape(1, -1)
+        res = self._solve_batch(p0, v0, goal, x0, self.precision)
         info = res["info"][0]
         converged = int(info["status"]) == 0                                     # result.success
         self.convergence_history.append(converged)
@@ -165,30 +174,33 @@ class SE3MPCPlanner(BasePlanner):
                                 fun=float(info["fun"]), message=TASK_MESSAGES.get(int(info["task"]), ""))
         if not converged:
             self.logger.warning("SE(3) MPC optimization did not converge: %s", self.last_result["message"])
+        if self.receding_horizon:
+            self.last_solution = {k: res[k][0].copy() for k in ("positions", "velocities", "thrust_vectors")}
         return {k: res[k][0] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes",
                                        "body_rates", "thrusts")}
 
     def _solve_batch(self, p0, v0, goal, x0, precision, want_trajectory=True) -> Dict[str, np.ndarray]:
-        """B problems in one launch; host float64 arrays in, host float64 arrays out."""
+        """B problems in one launch; host float64 arrays in, host float64 arrays out.  One H2D copy of
+        the stacked (p0, v0, goal), one launch, one D2H copy of the packed result."""
         import torch
         ops = self._get_ops()
         dev = ops.be.device
-        dt = torch.float32 if precision == "f32" else torch.float64
+        suf = "f32" if precision == "f32" else "f64"
+        dt = torch.float32 if suf == "f32" else torch.float64
         B, N = p0.shape[0], self.se3_config.prediction_horizon
         prm = self._params(has_goal=int(goal is not None))
-        pack = np.concatenate([p0, v0] + ([goal] if goal is not None else []), axis=0)
-        dpack = torch.from_numpy(np.ascontiguousarray(pack)).to(device=dev, dtype=dt)
-        dp0, dv0 = dpack[:B], dpack[B:2 * B]
-        dgoal = dpack[2 * B:3 * B] if goal is not None else None
+        pack = np.stack([p0, v0, goal if goal is not None else np.zeros_like(p0)])         # (3, B, 3)
+        dpack = torch.from_numpy(np.ascontiguousarray(pack, dtype=np.float32 if suf == "f32" else np.float64)).to(dev)
         dx0 = None if x0 is None else torch.from_numpy(np.ascontiguousarray(x0)).to(device=dev, dtype=dt)
-        out = ops.solve(prm, dp0, dv0, dgoal, x0=dx0, want_trajectory=want_trajectory)
-        x = out["x"].to(torch.float64).cpu().numpy()
-        res = dict(x=x, info=ops.info_to_host(out["info"]),
-                   positions=x[:, :3 * N].reshape(B, N, 3), velocities=x[:, 3 * N:6 * N].reshape(B, N, 3),
+        key = (B, N, suf)
+        if self._io.get("key") != key:
+            self._io = dict(key=key, out=ops.be.empty((ops.packed_size(B, N, suf),), "u8"))
+        out = ops.solve_packed(prm, dpack, x0=dx0, out=self._io["out"])
+        host = out.cpu().numpy()
+        res = ops.unpack_solution(host, B, N, suf)
+        x = res["x"]
+        res.update(positions=x[:, :3 * N].reshape(B, N, 3), velocities=x[:, 3 * N:6 * N].reshape(B, N, 3),
                    thrust_vectors=x[:, 6 * N:].reshape(B, N, 3))
-        if want_trajectory:
-            for k in ("accelerations", "attitudes", "body_rates", "thrusts"):
-                res[k] = out[k].to(torch.float64).cpu().numpy()
         return res
 
     # ------------------------------------------------------------------ batched extensions
@@ -223,6 +235,28 @@ class SE3MPCPlanner(BasePlanner):
         sol = {k: res[k][best] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes",
                                          "body_rates", "thrusts")}
         return self._create_trajectory_from_solution(sol, time.time())
+
+    def _create_warm_start(self, current_state: DroneState, N: int) -> np.ndarray:
+        """planner.py:294-327: shift the previous solution by one step, re-anchor step 0 at the current
+        state, extend to the goal with hover thrust."""
+        prev = self.last_solution
+        P = np.zeros((N, 3)); V = np.zeros((N, 3)); T = np.zeros((N, 3))
+        P[0] = to_float(current_state.position)
+        V[0] = to_float(current_state.velocity)
+        plen = len(prev["positions"]) if prev is not None else 0
+        shift = 0
+        if prev is not None and plen > 1:
+            shift = min(N - 1, plen - 1)
+            P[1:shift + 1] = prev["positions"][1:shift + 1]
+            V[1:shift + 1] = prev["velocities"][1:shift + 1]
+            T[:shift] = prev["thrust_vectors"][1:shift + 1]
+        if self.goal_position is not None:
+            shift = min(N - 1, plen - 1) if prev is not None else 0
+            for i in range(shift + 1, N):
+                alpha = (i - shift) / max(N - shift, 1)
+                P[i] = (1 - alpha) * P[shift] + alpha * self.goal_position
+                T[i] = (0.0, 0.0, self.hover_thrust)
+        return np.concatenate([P.ravel(), V.ravel(), T.ravel()])
 
     def _cold_start(self, p0, v0, goal) -> np.ndarray:
         """planner.py:329-359 on the host (only to seed restarts; the solver has its own)."""

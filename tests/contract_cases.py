@@ -169,6 +169,26 @@ def case_emergency_failsafe_handling(r: Rig):                              # :30
     assert np.allclose(state.position, r.initial_state.position, atol=0.5)
 
 
+def case_receding_horizon_warm_start(r: Rig, tol=1e-9):
+    """SURVEY.md section 8f-4 (beyond the 11 reference cases): with receding_horizon=True the second plan starts
+    from the reference's (dead-code) warm start; the result must equal SciPy run from that same x0."""
+    from oracle import se3mpc_oracle as orc
+    pl = r.planner
+    pl.receding_horizon = True
+    pl.plan_trajectory(r.initial_state, r.goal_position)
+    assert pl.last_solution is not None
+    s2 = DroneState(timestamp=r.initial_state.timestamp + 0.0025, position=np.array([0.02, 0.01, 1.01]),
+                    velocity=np.array([0.5, 0.3, 0.1]))
+    x0 = pl._create_warm_start(s2, 6)
+    tr = pl.plan_trajectory(s2, r.goal_position)
+    cfg = orc.OracleConfig()
+    xr, info = orc.solve(s2.position, s2.velocity, r.goal_position, cfg, x0=x0)
+    assert (pl.last_result["nit"], pl.last_result["nfev"], pl.last_result["status"]) == (info["nit"], info["nfev"], info["status"])
+    assert np.max(np.abs(tr.positions.ravel() - xr[:18])) <= tol
+    pl.receding_horizon = False
+    pl.last_solution = None
+
+
 ALL_CASES = [case_planner_outputs_complete_trajectory, case_controller_accepts_planner_outputs, case_closed_loop_simulation,
              case_body_rate_control_consistency, case_trajectory_interpolation, case_emergency_trajectory_handling,
              case_performance_benchmark, case_wind_disturbance, case_actuator_saturation, case_wind_gust,

@@ -33,6 +33,10 @@ def test_contract_case(attach, case):
         case(rig)
 
 
+def test_receding_horizon_warm_start(attach):
+    cc.case_receding_horizon_warm_start(cc.Rig(attach))
+
+
 def test_planner_refuses_to_run_without_a_gpu():
     """No CPU fallback: on a box without a HIP device the first plan raises."""
     import torch

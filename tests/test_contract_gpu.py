@@ -21,3 +21,10 @@ def test_contract_case(case, precision):
     else:
         case(rig)
     assert rig.planner._get_ops().lib.path.endswith("libse3mpc.so")
+
+
+@pytest.mark.parametrize("precision,tol", [("f64", 1e-9), ("f32", 1e-4)])
+def test_receding_horizon_warm_start(precision, tol):
+    def attach(planner):
+        planner.precision = precision
+    cc.case_receding_horizon_warm_start(cc.Rig(attach), tol=tol)
