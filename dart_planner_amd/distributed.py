@@ -56,7 +56,12 @@ def allreduce_min_keys(keys):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return keys
     keys ^= _SIGN
-    dist.all_reduce(keys, op=dist.ReduceOp.MIN)
+    if dist.get_backend() == "gloo" and keys.is_cuda:      # rehearsal on one GPU: gloo reduces through the host
+        h = keys.cpu()
+        dist.all_reduce(h, op=dist.ReduceOp.MIN)
+        keys.copy_(h)
+    else:
+        dist.all_reduce(keys, op=dist.ReduceOp.MIN)
     keys ^= _SIGN
     return keys
 
