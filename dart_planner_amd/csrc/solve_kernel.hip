@@ -28,7 +28,7 @@ constexpr double kBig = 1.0e10;
 constexpr double kInf = __builtin_huge_val();
 
 struct SolveDev {
-  int N, n, has_goal, m, maxiter, maxls, maxfun;
+  int N, n, has_goal, m, mlds, only_overflow, maxiter, maxls, maxfun;
   double dt, mass, grav, hover, wp, wv, wa, wT, term;
   double pos_b, v_max, txy, tz_lo, tz_hi;
   double pgtol, ftol;
@@ -37,6 +37,7 @@ struct SolveDev {
 static SolveDev make_solve_dev(const se3mpc_params& p) {
   SolveDev d;
   d.N = p.horizon; d.n = 9 * p.horizon; d.has_goal = p.has_goal; d.m = p.max_corrections;
+  d.mlds = p.max_corrections; d.only_overflow = 0;
   d.maxiter = p.max_iterations; d.maxls = p.max_linesearch; d.maxfun = p.max_fun;
   d.dt = p.dt; d.mass = p.mass; d.grav = p.gravity; d.hover = p.mass * p.gravity;
   d.wp = p.position_weight; d.wv = p.velocity_weight; d.wa = p.acceleration_weight; d.wT = p.thrust_weight;
@@ -245,7 +246,14 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
   const int lane = lane_id();
   const int pb = blockIdx.x;               // problem index
-  const int n = q.n, N = q.N, m = q.m, npad = kWave * J;
+  const int n = q.n, N = q.N, npad = kWave * J;
+  // Two-tier memory: the first launch gives every problem LDS for `mlds` (<= 4) L-BFGS pairs, which is all a
+  // solve with the reference's options ever stores (it stops after 1-3 iterations) and doubles the
+  // wavefronts a CU can hold; a problem that needs a pair more leaves with task = SE3MPC_TASK_OVERFLOW and
+  // is re-solved from scratch by the second launch (mlds = maxcor, only_overflow = 1), in which every other
+  // wavefront exits at once.  `m` below is the STORAGE bound; the algorithm's memory is still q.m.
+  if (q.only_overflow && infog[pb].task != SE3MPC_TASK_OVERFLOW) return;
+  const int m = q.mlds;
   // LDS carve-up: doubles first, then the S / Y pairs in the IO type
   double* sy = reinterpret_cast<double*>(lds_raw);     // [m][m]  S'Y (lower triangle used)
   double* ss = sy + m * m;                             // [m][m]  S'S (upper triangle used)
@@ -770,6 +778,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     }
     if (dr <= kEps * ddum) continue;                    // skip the update
     ++iupdat;
+    if (iupdat > m && m < q.m) { task = SE3MPC_TASK_OVERFLOW; status = 1; break; }   // second tier re-solves this problem
     if (iupdat <= m) col = iupdat;
     else {
       // memory full: drop the oldest pair (each lane shifts its own elements; lane 0 the small matrices)
@@ -899,21 +908,32 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   if (B < 0) return SE3MPC_ERR_SHAPE;
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !X || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
-  const SolveDev q = make_solve_dev(*p);
+  SolveDev q = make_solve_dev(*p);
   const int n = q.n;
   const int Jneed = (n + kWave - 1) / kWave;
   hipStream_t s = (hipStream_t)stream;
-#define SE3MPC_SOLVE_CASE(JJ)                                                                                         \
-  hipLaunchKernelGGL((solve_kernel<IO, JJ>), dim3(B), dim3(kWave), solve_lds_bytes(q.m, JJ, sizeof(IO)), s, q, B, p0, \
+#define SE3MPC_SOLVE_CASE(JJ)                                                                                            \
+  hipLaunchKernelGGL((solve_kernel<IO, JJ>), dim3(B), dim3(kWave), solve_lds_bytes(q.mlds, JJ, sizeof(IO)), s, q, B, p0, \
                      v0, goal, x0, X, info, acc, att, rates, thrust)
-  if (Jneed <= 1) SE3MPC_SOLVE_CASE(1);
-  else if (Jneed <= 2) SE3MPC_SOLVE_CASE(2);
-  else if (Jneed <= 3) SE3MPC_SOLVE_CASE(3);
-  else if (Jneed <= 5) SE3MPC_SOLVE_CASE(5);
-  else if (Jneed <= 8) SE3MPC_SOLVE_CASE(8);
-  else SE3MPC_SOLVE_CASE(9);
+#define SE3MPC_SOLVE_LAUNCH()                  \
+  if (Jneed <= 1) SE3MPC_SOLVE_CASE(1);        \
+  else if (Jneed <= 2) SE3MPC_SOLVE_CASE(2);   \
+  else if (Jneed <= 3) SE3MPC_SOLVE_CASE(3);   \
+  else if (Jneed <= 5) SE3MPC_SOLVE_CASE(5);   \
+  else if (Jneed <= 8) SE3MPC_SOLVE_CASE(8);   \
+  else SE3MPC_SOLVE_CASE(9)
+  constexpr int kFastPairs = 4;
+  const bool two_tier = info != nullptr && q.m > kFastPairs;    // the tiers talk through info[].task
+  q.mlds = two_tier ? kFastPairs : q.m;
+  SE3MPC_SOLVE_LAUNCH();
+  rc = launch_status("se3mpc_solve");
+  if (rc != SE3MPC_OK || !two_tier) return rc;
+  q.mlds = q.m;
+  q.only_overflow = 1;
+  SE3MPC_SOLVE_LAUNCH();
+#undef SE3MPC_SOLVE_LAUNCH
 #undef SE3MPC_SOLVE_CASE
-  return launch_status("se3mpc_solve");
+  return launch_status("se3mpc_solve(second tier)");
 }
 
 }  // namespace se3mpc

@@ -97,7 +97,8 @@ enum se3mpc_task {
   SE3MPC_TASK_CONV_FTOL = 2,     /* CONVERGENCE: REL_REDUCTION_OF_F <= FACTR*EPSMCH       */
   SE3MPC_TASK_STOP_MAXITER = 3,  /* STOP: TOTAL NO. OF ITERATIONS REACHED LIMIT           */
   SE3MPC_TASK_STOP_MAXFUN = 4,   /* STOP: TOTAL NO. OF F,G EVALUATIONS EXCEEDS LIMIT      */
-  SE3MPC_TASK_ABNORMAL = 5       /* ABNORMAL TERMINATION IN LNSRCH                        */
+  SE3MPC_TASK_ABNORMAL = 5,      /* ABNORMAL TERMINATION IN LNSRCH                        */
+  SE3MPC_TASK_OVERFLOW = 6       /* internal: first-tier LDS too small, re-solved by the second launch; never returned */
 };
 
 /* ------------------------------------------------------------------ library / params */
