@@ -238,8 +238,10 @@ __device__ int bmv(const double* sy, const double* wt, int m, int col, const dou
 }
 
 // ---- the solver ------------------------------------------------------------------------------
+// 2nd launch-bounds argument = wavefronts per SIMD the register allocation must leave room for: two
+// resident solves per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
 template <typename IO, int J>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, (J <= 5 ? 2 : 1))
 solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict__ v0g, const IO* __restrict__ goalg,
              const IO* __restrict__ x0g, IO* __restrict__ Xg, se3mpc_solve_info* __restrict__ infog,
              IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg) {
