@@ -51,10 +51,13 @@ out = {"rollout_fused_64x8192_graph": durations(tr, 64), "rollout_single_8192_gr
        "solve_kernel_single_problem": None, "solve_kernel_batch_8192": None}
 sv = rows_of("solve", "solve_kernel")
 if sv:
-    one = [r for r in sv if int(r["Grid_Size_X"]) == 64]
-    many = [r for r in sv if int(r["Grid_Size_X"]) == 64 * B]
-    out["solve_kernel_single_problem"] = durations(one)
-    out["solve_kernel_batch_8192"] = durations(many)
+    # every solve is two back-to-back launches: tier 1 (LDS for 4 L-BFGS pairs, all problems) and tier 2 (full LDS,
+    # every wavefront but the overflowed ones exits at once): alternate dispatches of the same grid
+    for name, grid in (("single_problem", 64), ("batch_8192", 64 * B)):
+        grp = sorted((r for r in sv if int(r["Grid_Size_X"]) == grid), key=lambda r: int(r["Dispatch_Id"]))
+        out[f"solve_kernel_{name}_tier1"] = durations(grp[0::2])
+        out[f"solve_kernel_{name}_tier2_empty"] = durations(grp[1::2])
+    del out["solve_kernel_single_problem"], out["solve_kernel_batch_8192"]
 for tag, rollouts, gy in (("fused", 64 * B, 64), ("single", B, None), ("b4m", 4194304, None)):
     alg_r = 4 * (3 * N + 9) * rollouts
     alg_w = 4 * (3 * N + 1) * rollouts
