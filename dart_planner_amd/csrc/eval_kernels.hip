@@ -619,6 +619,52 @@ reduce_keys_kernel(const unsigned long long* __restrict__ wave_keys, int per_bat
 }
 
 // ------------------------------------------------------------------------------------------
+// Obstacle source: occupancy grid -> sphere table, on the device.
+// Replaces the selection of cloud/main_improved_threelayer.py:387-398 (and of
+// tests/test_se3_mpc_with_mapper.py:29-33): occupied = grid[occ > threshold] in grid order,
+// step = max(1, n // target), spheres = occupied[::step] with a fixed radius.  One 256-thread workgroup;
+// wavefront w owns a contiguous quarter of the grid and walks it 64 cells at a time (coalesced), ranking
+// occupied cells with ballot + popcount; the four wavefront totals meet in LDS.  Deterministic order.
+// ------------------------------------------------------------------------------------------
+template <typename R>
+__global__ void __launch_bounds__(256)
+spheres_from_grid_kernel(const R* __restrict__ pos, const R* __restrict__ occ, int M, R threshold, int target, R radius,
+                         R* __restrict__ spheres, int cap, int32_t* __restrict__ count) {
+  __shared__ int wave_total[4];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const int seg = ((M + 3) / 4 + kWave - 1) / kWave * kWave;          // per-wavefront segment, multiple of 64
+  const int lo = wave * seg, hi = (lo + seg < M) ? lo + seg : M;
+  int mine = 0;
+  for (int i0 = lo; i0 < hi; i0 += kWave) {
+    const int i = i0 + lane;
+    const bool o = i < hi && occ[i] > threshold;
+    mine += __builtin_popcountll(wave_ballot(o));
+  }
+  if (lane == 0) wave_total[wave] = mine;
+  __syncthreads();
+  int rank = 0, total = 0;
+  for (int w = 0; w < 4; ++w) { if (w < wave) rank += wave_total[w]; total += wave_total[w]; }
+  const int step = (target > 0 && total / target > 1) ? total / target : 1;
+  for (int i0 = lo; i0 < hi; i0 += kWave) {
+    const int i = i0 + lane;
+    const bool o = i < hi && occ[i] > threshold;
+    const uint64_t m = wave_ballot(o);
+    if (o) {
+      const int r = rank + __builtin_popcountll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+      if (r % step == 0 && r / step < cap) {
+        R* s4 = spheres + (size_t)4 * (r / step);
+        s4[0] = pos[(size_t)3 * i]; s4[1] = pos[(size_t)3 * i + 1]; s4[2] = pos[(size_t)3 * i + 2]; s4[3] = radius;
+      }
+    }
+    rank += __builtin_popcountll(m);
+  }
+  if (threadIdx.x == 0) {
+    const int k = total == 0 ? 0 : (total + step - 1) / step;
+    *count = k < cap ? k : cap;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // [rows][ld_in] -> [cols][ld_out] transpose through a padded LDS tile
 // ------------------------------------------------------------------------------------------
 template <typename R>
@@ -828,6 +874,16 @@ int argmin_impl(int B, const R* cost, uint32_t index_base, uint64_t* key, void* 
 }
 
 template <typename R>
+int spheres_from_grid_impl(const R* pos, const R* occ, int M, double threshold, int target, double radius, R* spheres, int cap,
+                           int32_t* count, void* stream) {
+  if (M < 0 || cap < 0 || target < 1) return SE3MPC_ERR_SHAPE;
+  if (!count || (M > 0 && (!pos || !occ)) || (cap > 0 && !spheres)) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(spheres_from_grid_kernel<R>, dim3(1), dim3(256), 0, (hipStream_t)stream, pos, occ, M, (R)threshold,
+                     target, (R)radius, spheres, cap, count);
+  return launch_status("se3mpc_spheres_from_grid");
+}
+
+template <typename R>
 int transpose_impl(int rows, int cols, const R* in, int ld_in, R* out, int ld_out, void* stream) {
   if (rows < 0 || cols < 0 || ld_in < cols || ld_out < rows) return SE3MPC_ERR_SHAPE;
   if (rows == 0 || cols == 0) return SE3MPC_OK;
@@ -886,6 +942,10 @@ using namespace se3mpc;
   }                                                                                                                      \
   extern "C" int se3mpc_argmin_##SUF(int B, const R* cost, uint32_t index_base, uint64_t* key, void* stream) {            \
     return argmin_impl<R>(B, cost, index_base, key, stream);                                                             \
+  }                                                                                                                      \
+  extern "C" int se3mpc_spheres_from_grid_##SUF(const R* positions, const R* occupancy, int M, double threshold, int target, \
+                                                double radius, R* spheres, int cap, int32_t* count, void* stream) {     \
+    return spheres_from_grid_impl<R>(positions, occupancy, M, threshold, target, radius, spheres, cap, count, stream);   \
   }                                                                                                                      \
   extern "C" int se3mpc_transpose_##SUF(int rows, int cols, const R* in, int ld_in, R* out, int ld_out, void* stream) {   \
     return transpose_impl<R>(rows, cols, in, ld_in, out, ld_out, stream);                                                \

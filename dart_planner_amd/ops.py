@@ -256,6 +256,23 @@ class Ops:
         k = int(self.be.to_host(key).reshape(-1)[0]) & 0xFFFFFFFFFFFFFFFF
         return self.lib.key_index(k), self.lib.key_cost(k)
 
+    def spheres_from_grid(self, positions, occupancy, threshold: float = 0.6, target: int = 20, radius: float = 1.0,
+                          cap: int = 64):
+        """Occupancy grid -> sphere table on the device (f-2).  positions (M, 3), occupancy (M,) in the
+        mapper's grid order.  -> (spheres (cap, 4), count int32 (1,)); rows >= count are unspecified."""
+        self.be.check(positions, "positions"); self.be.check(occupancy, "occupancy")
+        M = occupancy.shape[0]
+        if tuple(positions.shape) != (M, 3):
+            raise ValueError(f"positions: expected ({M}, 3), got {tuple(positions.shape)}")
+        suf = self.be.suffix(positions)
+        if self.be.suffix(occupancy) != suf:
+            raise ValueError("positions and occupancy must share a dtype")
+        spheres = self.be.empty((cap, 4), suf)
+        count = self.be.empty((1,), "i32")
+        self.lib.call("spheres_from_grid", suf, self.be.ptr(positions), self.be.ptr(occupancy), M, float(threshold),
+                      int(target), float(radius), self.be.ptr(spheres), cap, self.be.ptr(count), self.be.stream())
+        return spheres, count
+
     def transpose(self, a):
         """(rows, cols) -> (cols, rows), through the LDS-tiled kernel."""
         self.be.check(a, "a")

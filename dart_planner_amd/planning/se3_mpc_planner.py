@@ -271,6 +271,28 @@ class SE3MPCPlanner(BasePlanner):
         T[:, 2] = self.hover_thrust
         return np.concatenate([P.ravel(), V.ravel(), T.ravel()])
 
+    def refresh_obstacles_from_grid(self, grid_positions, occupancies, threshold: float = 0.6, target: int = 20,
+                                    radius: float = 1.0) -> int:
+        """What the cloud loop does between mapper and planner
+        (cloud/main_improved_threelayer.py:381-398 ``_refresh_se3_obstacles_from_mapper``): clear the obstacle
+        list and refill it with every step-th occupied grid cell as a sphere of fixed radius -- selected on
+        the device (``se3mpc_spheres_from_grid_*``).  ``grid_positions`` / ``occupancies`` are the two
+        arrays ``ExplicitGeometricMapper.get_local_occupancy_grid`` returns (any shape that flattens to
+        (M, 3) / (M,)).  Returns the number of obstacles."""
+        import torch
+        ops = self._get_ops()
+        dev = ops.be.device
+        pos = torch.as_tensor(np.ascontiguousarray(np.asarray(to_float(grid_positions), float).reshape(-1, 3))).to(dev)
+        occ = torch.as_tensor(np.ascontiguousarray(np.asarray(to_float(occupancies), float).reshape(-1))).to(dev)
+        spheres, count = ops.spheres_from_grid(pos, occ, threshold=threshold, target=target, radius=radius,
+                                               cap=max(2 * target, 1))
+        k = int(count.cpu()[0])
+        sp = spheres[:k].cpu().numpy()
+        self.clear_obstacles()
+        for row in sp:
+            self.add_obstacle(row[:3].copy(), float(row[3]))
+        return k
+
     def obstacle_clearance(self, trajectory: Trajectory) -> Dict[str, float]:
         """planner.py:499-514 evaluated on a planned trajectory with the obstacle kernel: the minimum
         of |p_k - c_j|^2 - (r_j + margin)^2 over steps and obstacles (>= 0 means clear) and the summed

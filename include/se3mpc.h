@@ -216,6 +216,18 @@ int se3mpc_argmin_f64(int B, const double* cost, uint32_t index_base, uint64_t* 
 uint32_t se3mpc_key_index(uint64_t key);
 float se3mpc_key_cost(uint64_t key);   /* f64 costs are ordered through their float rounding */
 
+/* Obstacle source: the sphere table of se3mpc_obstacle_residual_* straight from a local
+ * occupancy grid, replacing the host loop of cloud/main_improved_threelayer.py:387-398 (target 20) and
+ * tests/test_se3_mpc_with_mapper.py:29-33 (target 10): occupied = cells with occupancy > threshold in grid
+ * order, step = max(1, n_occupied // target), spheres = every step-th occupied cell, all with `radius`.
+ * positions: [M][3] (grid order of ExplicitGeometricMapper.get_local_occupancy_grid,
+ * perception/explicit_geometric_mapper.py:221-248), occupancy: [M]; spheres: [cap][4] (at most 2*target-1
+ * are produced; extra ones are dropped at cap), *count = number written. */
+int se3mpc_spheres_from_grid_f32(const float* positions, const float* occupancy, int M, double threshold, int target,
+                                 double radius, float* spheres, int cap, int32_t* count, void* stream);
+int se3mpc_spheres_from_grid_f64(const double* positions, const double* occupancy, int M, double threshold, int target,
+                                 double radius, double* spheres, int cap, int32_t* count, void* stream);
+
 /* [rows][ld_in] <-> [cols][ld_out] tiled transpose through LDS (layout conversion). */
 int se3mpc_transpose_f32(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, void* stream);
 int se3mpc_transpose_f64(int rows, int cols, const double* in, int ld_in, double* out, int ld_out, void* stream);

@@ -394,3 +394,27 @@ def rollout_cost_grad(p0, v0, goal, T, cfg: OracleConfig):
         lamV = 2 * wv * V[..., k, :] + dt * lamP + lamV
         lamP = 2 * wp * (P[..., k, :] - goal) + lamP
     return cost, G
+
+
+# --------------------------------------------------------------------------- f-2: obstacle source
+def local_grid_positions(centre, size: float, resolution: float) -> np.ndarray:
+    """Grid cell centres in the order of ExplicitGeometricMapper.get_local_occupancy_grid
+    (perception/explicit_geometric_mapper.py:221-248), flattened to (M, 3)."""
+    centre = np.asarray(centre, float)
+    half = size / 2
+    n = int(size / resolution)
+    x, y, z = (np.linspace(centre[a] - half, centre[a] + half, n) for a in range(3))
+    return np.array(np.meshgrid(x, y, z)).T.reshape(-1, 3)
+
+
+def spheres_from_grid(grid_positions, occupancy, threshold: float = 0.6, target: int = 20, radius: float = 1.0) -> np.ndarray:
+    """cloud/main_improved_threelayer.py:387-398 (target 20) / tests/test_se3_mpc_with_mapper.py:29-33
+    (target 10): every step-th occupied cell becomes a sphere of fixed radius.  -> (K, 4)."""
+    pts = np.asarray(grid_positions, float).reshape(-1, 3)
+    occ = np.asarray(occupancy, float).reshape(-1)
+    occupied = pts[occ > threshold]
+    if occupied.size == 0:
+        return np.zeros((0, 4))
+    step = max(1, occupied.shape[0] // target)
+    chosen = occupied[::step]
+    return np.concatenate([chosen, np.full((len(chosen), 1), radius)], axis=1)

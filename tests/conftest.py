@@ -33,3 +33,10 @@ def golden_path():
     data = np.load(os.path.join(GOLDEN, "path_functions.npz"))
     meta = json.load(open(os.path.join(GOLDEN, "path_functions.json")))
     return data, meta
+
+
+@pytest.fixture(scope="session")
+def golden_mapper():
+    data = np.load(os.path.join(GOLDEN, "mapper_spheres.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "mapper_spheres.json")))
+    return data, meta

@@ -247,6 +247,37 @@ def main():
             json.dump(dict(scipy=scipy.__version__, numpy=np.__version__, cases=meta, valid=valid_cases,
                            constants=dict(mass=float(pl.mass), gravity=float(pl.gravity),
                                           hover=float(pl.hover_thrust), default_dt=1.0 / 400.0)), f, indent=1)
+        # ---------------------------------------------- obstacle source: mapper -> sphere list
+        from dart_planner.perception.explicit_geometric_mapper import ExplicitGeometricMapper
+        import contextlib, io
+        out = {}
+        meta = []
+        scenes = [
+            ("dense", [([3.0, 1.0, 2.0], 1.6), ([-4.0, -2.5, 1.0], 2.2), ([6.5, 6.0, 4.0], 1.1), ([0.5, -6.0, 3.5], 0.9)], [0.0, 0.0, 2.0], 20.0, 20),
+            ("sparse", [([2.0, 2.0, 2.0], 0.6)], [0.0, 0.0, 2.0], 20.0, 20),
+            ("empty", [], [1.0, -1.0, 3.0], 20.0, 20),
+            ("test_file_divisor", [([3.0, 0.0, 3.0], 1.5), ([7.0, 1.0, 4.0], 1.0)], [0.0, 0.0, 2.0], 15.0, 10),
+        ]
+        for tag, obstacles, centre, size, target in scenes:
+            with contextlib.redirect_stdout(io.StringIO()):
+                mapper = ExplicitGeometricMapper(resolution=0.5, max_range=40.0)      # tests/test_se3_mpc_with_mapper.py:12
+            for c_, r_ in obstacles:
+                mapper.add_obstacle(np.array(c_, float), r_)
+            grid, occ = mapper.get_local_occupancy_grid(np.array(centre, float), size=size)
+            # the three selection lines of cloud/main_improved_threelayer.py:387-398 (target 20) and of
+            # tests/test_se3_mpc_with_mapper.py:29-33 (target 10), applied to the reference mapper's own output
+            occupied_points = grid[occ > 0.6]
+            step = max(1, occupied_points.shape[0] // target)
+            chosen = occupied_points[::step] if occupied_points.size else np.zeros((0, 3))
+            k = f"m_{tag}_"
+            out[k + "grid"] = grid.reshape(-1, 3)
+            out[k + "occ"] = occ.reshape(-1)
+            out[k + "spheres"] = np.concatenate([chosen, np.ones((len(chosen), 1))], axis=1)
+            meta.append(dict(key=k, centre=centre, size=size, resolution=0.5, target=target, n_occupied=int(occupied_points.shape[0]),
+                             n_spheres=int(len(chosen)), num_cells=int(grid.shape[0])))
+        np.savez_compressed(os.path.join(HERE, "mapper_spheres.npz"), **out)
+        with open(os.path.join(HERE, "mapper_spheres.json"), "w") as f:
+            json.dump(dict(cases=meta), f, indent=1)
         print("wrote", os.listdir(HERE))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)

@@ -254,3 +254,32 @@ def check_solver_vs_oracle(h: Harness, N: int, B: int, seed: int = 11, **overrid
         if same:
             worst = max(worst, float(np.max(np.abs(X[i, :3 * N] - xr[:3 * N]))))
     return worst, mism / B
+
+
+# --------------------------------------------------------------------------------------- f-2
+def check_spheres_from_grid(h: Harness, data, meta):
+    """Occupancy grid (produced by the reference's mapper) -> sphere table, against the reference's selection."""
+    for c in meta["cases"]:
+        k = c["key"]
+        grid, occ, exp = data[k + "grid"], data[k + "occ"], data[k + "spheres"]
+        assert np.allclose(orc.local_grid_positions(c["centre"], c["size"], c["resolution"]), grid, rtol=0, atol=1e-12), k
+        assert np.array_equal(orc.spheres_from_grid(grid, occ, target=c["target"]), exp), k
+        spheres, count = h.ops.spheres_from_grid(h.prob(grid), h.prob(occ), threshold=0.6, target=c["target"], radius=1.0, cap=64)
+        n = int(h.to_host(count)[0])
+        assert n == c["n_spheres"] == len(exp), (k, n)
+        got = h.to_host(spheres)[:n].astype(float)
+        assert np.array_equal(got, exp.astype(h.dt).astype(float)), k          # copies of grid points: exact
+    # cap smaller than the selection: the first `cap` spheres, count == cap
+    c = meta["cases"][0]
+    spheres, count = h.ops.spheres_from_grid(h.prob(data[c["key"] + "grid"]), h.prob(data[c["key"] + "occ"]), target=c["target"], cap=5)
+    assert int(h.to_host(count)[0]) == 5
+    assert np.array_equal(h.to_host(spheres).astype(float), data[c["key"] + "spheres"][:5].astype(h.dt).astype(float))
+    # ragged sizes: M not a multiple of the 256-cell stride, and M == 0
+    rng = np.random.default_rng(1)
+    for M in (0, 1, 63, 64, 65, 255, 257, 1000):
+        grid = rng.uniform(-5, 5, (M, 3)); occ = rng.choice([0.5, 0.9], M, p=[0.7, 0.3])
+        exp = orc.spheres_from_grid(grid, occ, target=7)
+        spheres, count = h.ops.spheres_from_grid(h.prob(grid), h.prob(occ), target=7, cap=32)
+        n = int(h.to_host(count)[0])
+        assert n == len(exp), (M, n, len(exp))
+        assert np.array_equal(h.to_host(spheres)[:n].astype(float), exp.astype(h.dt).astype(float)), M

@@ -54,6 +54,11 @@ def test_solver_extraction_and_cold_start(emu_ops):
     pc.check_solver_extraction(harness(emu_ops, np.float32), 20, 3)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_spheres_from_grid(emu_ops, golden_mapper, dt):
+    pc.check_spheres_from_grid(harness(emu_ops, dt), *golden_mapper)
+
+
 def test_empty_batch_and_error_codes(emu_ops):
     lib, be = emu_ops.lib, emu_ops.be
     prm = capi.Params.reference_defaults(horizon=6)

@@ -147,6 +147,30 @@ def test_monte_carlo_restarts_f64_vs_f32(gpu_ops):
     assert np.max(np.abs(cold - x64.reshape(S, Rr, -1)[:, 0])) <= 1e-9
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_spheres_from_grid(gpu_ops, golden_mapper, dt):
+    pc.check_spheres_from_grid(harness(gpu_ops, dt), *golden_mapper)
+
+
+def test_planner_obstacles_from_mapper_grid(gpu_ops, golden_mapper):
+    """The cloud loop's mapper -> planner hand-off (main_improved_threelayer.py:381-398) through the mirror."""
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCPlanner
+    from dart_planner_amd.common.types import DroneState, Trajectory
+    data, meta = golden_mapper
+    c = meta["cases"][0]
+    pl = SE3MPCPlanner()
+    nc = c["num_cells"]
+    k = pl.refresh_obstacles_from_grid(data[c["key"] + "grid"].reshape(nc, nc, nc, 3), data[c["key"] + "occ"].reshape(nc, nc, nc))
+    exp = data[c["key"] + "spheres"]
+    assert k == len(exp) == len(pl.obstacles)
+    assert all(np.array_equal(o[0], e[:3]) and o[1] == 1.0 for o, e in zip(pl.obstacles, exp))
+    tr = pl.plan_trajectory(DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 2.0])), np.array([10.0, 0.0, 5.0]))
+    clr = pl.obstacle_clearance(tr)
+    P = np.asarray(tr.positions)
+    ref = min(np.sum((P[i] - o[0]) ** 2) - (o[1] + 1.5) ** 2 for i in range(len(P)) for o in pl.obstacles)
+    assert abs(clr["min_residual"] - ref) <= 1e-9
+
+
 def test_wave_ops_selftest(gpu_ops):
     """The DPP reductions behind every dot product of the solver, on known data."""
     import torch
