@@ -283,3 +283,32 @@ def check_spheres_from_grid(h: Harness, data, meta):
         n = int(h.to_host(count)[0])
         assert n == len(exp), (M, n, len(exp))
         assert np.array_equal(h.to_host(spheres)[:n].astype(float), exp.astype(h.dt).astype(float)), M
+
+
+# --------------------------------------------------------------------------------------- robustness
+def check_solver_edge_inputs(h: Harness):
+    """(1) goal_position None (planner.py:524/:546/:567 skip the goal terms) against the oracle;
+    (2) NaN / Inf / denormal inputs: every wavefront must terminate with a SciPy-style status --
+    a wavefront that never exits would hang the GPU."""
+    prm = Params.reference_defaults(horizon=6, has_goal=0)
+    p0, v0 = np.array([[1.0, 2.0, 3.0]]), np.array([[0.5, -0.2, 0.1]])
+    out = h.ops.solve(prm, h.prob(p0), h.prob(v0), None)
+    xr, ir = orc.solve(p0[0].astype(h.dt).astype(float), v0[0].astype(h.dt).astype(float), None, orc.OracleConfig())
+    info = h.ops.info_to_host(out["info"])[0]
+    assert (int(info["nit"]), int(info["nfev"]), int(info["status"])) == (ir["nit"], ir["nfev"], ir["status"])
+    assert np.max(np.abs(h.to_host(out["x"])[0] - xr)) <= h.tol["pos"]
+    prm = Params.reference_defaults(horizon=6)
+    bad = [np.nan, np.inf, -np.inf, 1e30, 1e-320]
+    rows = [(b, w) for b in bad for w in range(3)]
+    P0 = np.tile([0.0, 0.0, 1.0], (len(rows), 1)); V0 = np.zeros((len(rows), 3)); G = np.tile([5.0, 3.0, 2.0], (len(rows), 1))
+    with np.errstate(over="ignore"):
+        for i, (b, w) in enumerate(rows):
+            (P0, V0, G)[w][i, 1] = b
+        out = h.ops.solve(prm, h.prob(P0), h.prob(V0), h.prob(G))
+    info = h.ops.info_to_host(out["info"])
+    assert set(np.unique(info["status"])) <= {0, 1, 2} and np.all(info["task"] >= 1) and np.all(info["task"] <= 5)
+    assert np.all(info["nfev"] <= 2 + prm.max_iterations * (prm.max_linesearch + 1))
+    # a non-finite state is projected into the box, a non-finite goal ends in ABNORMAL (f is NaN/Inf)
+    finite_goal = np.isfinite(G).all(axis=1)
+    assert np.all(np.isfinite(h.to_host(out["x"])[finite_goal]))
+    assert np.all(info["status"][~finite_goal] == 2)

@@ -59,6 +59,11 @@ def test_spheres_from_grid(emu_ops, golden_mapper, dt):
     pc.check_spheres_from_grid(harness(emu_ops, dt), *golden_mapper)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_edge_inputs(emu_ops, dt):
+    pc.check_solver_edge_inputs(harness(emu_ops, dt))
+
+
 def test_empty_batch_and_error_codes(emu_ops):
     lib, be = emu_ops.lib, emu_ops.be
     prm = capi.Params.reference_defaults(horizon=6)

@@ -171,6 +171,81 @@ def test_planner_obstacles_from_mapper_grid(gpu_ops, golden_mapper):
     assert abs(clr["min_residual"] - ref) <= 1e-9
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_edge_inputs(gpu_ops, dt):
+    pc.check_solver_edge_inputs(harness(gpu_ops, dt))
+
+
+def test_entry_points_are_graph_capturable(gpu_ops):
+    """The library never allocates or synchronises: a solve and a rollout captured into a hipGraph replay
+    to the same results as the eager calls."""
+    import torch
+    from dart_planner_amd.capi import Params
+    ops = gpu_ops
+    dev = ops.be.device
+    N, B = 20, 300
+    prm = Params.reference_defaults(horizon=N)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    p0 = torch.rand(B, 3, device=dev, generator=g) * 40 - 20
+    v0 = torch.rand(B, 3, device=dev, generator=g) * 10 - 5
+    goal = torch.rand(B, 3, device=dev, generator=g) * 40 - 20
+    eager = ops.solve(prm, p0, v0, goal)
+    xe, ie = eager["x"].clone(), ops.info_to_host(eager["info"]).copy()
+    buf = ops.be.empty((ops.packed_size(B, N, "f32"),), "u8")
+    inputs = torch.stack([p0, v0, goal]).contiguous()
+    side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            ops.solve_packed(prm, inputs, out=buf)
+    torch.cuda.current_stream().wait_stream(side)
+    buf.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    res = ops.unpack_solution(buf.cpu().numpy(), B, N, "f32")
+    assert np.array_equal(res["x"], xe.cpu().numpy().astype(np.float64))
+    assert np.array_equal(res["info"]["nfev"], ie["nfev"]) and np.array_equal(res["info"]["fun"], ie["fun"])
+
+
+def test_monte_carlo_full_size(gpu_ops):
+    """BASELINE.json config 5 at full size: 4096 initial states x 256 restarts = 1 048 576 solves (f32) in one
+    launch.  Checked through properties: restart 0 of every state equals the plain cold-start solve; every
+    solve ends with a SciPy status; the best restart's objective is <= the cold start's; a 4096-solve f64
+    sample agrees with f32 to the north_star tolerance."""
+    import torch
+    from dart_planner_amd.capi import Params
+    ops = gpu_ops
+    dev = ops.be.device
+    N, S, Rr = 6, 4096, 256
+    prm = Params.reference_defaults(horizon=N)
+    g = torch.Generator(device=dev); g.manual_seed(7)
+    p0 = torch.rand(S, 3, device=dev, generator=g) * 40 - 20
+    v0 = torch.rand(S, 3, device=dev, generator=g) * 10 - 5
+    goal = torch.rand(S, 3, device=dev, generator=g) * 40 - 20
+    cold = ops.solve(prm, p0, v0, goal, want_trajectory=False)
+    lane = lambda a: a.t().contiguous()
+    x0 = ops.transpose(ops.init(prm, lane(p0), lane(v0), lane(goal)))                         # (S, 9N) cold starts
+    X0 = x0[:, None, :].repeat(1, Rr, 1)
+    X0[:, 1:, 6 * N:] += torch.randn(S, Rr - 1, 3 * N, device=dev, generator=g)
+    rep = lambda a: a[:, None, :].repeat(1, Rr, 1).reshape(S * Rr, 3).contiguous()
+    out = ops.solve(prm, rep(p0), rep(v0), rep(goal), x0=X0.reshape(S * Rr, 9 * N).contiguous(), want_trajectory=False)
+    info = ops.info_to_host(out["info"]).reshape(S, Rr)
+    assert set(np.unique(info["status"])) <= {0, 1, 2}
+    x = out["x"].reshape(S, Rr, 9 * N)
+    assert float((x[:, 0] - cold["x"]).abs().max()) <= 1e-4
+    fun = info["fun"]
+    assert np.all(fun.min(axis=1) <= fun[:, 0] + 1e-9)
+    sub = slice(0, 16)
+    d = lambda a: a.double().contiguous()
+    o64 = ops.solve(prm, d(rep(p0[sub])), d(rep(v0[sub])), d(rep(goal[sub])), x0=d(X0[sub].reshape(-1, 9 * N)), want_trajectory=False)
+    i64 = ops.info_to_host(o64["info"])
+    same = (i64["nit"] == info[sub].reshape(-1)["nit"]) & (i64["nfev"] == info[sub].reshape(-1)["nfev"])
+    assert same.mean() >= 0.98
+    err = (o64["x"] - x[sub].reshape(-1, 9 * N).double()).abs()[torch.from_numpy(same).to(dev)][:, :3 * N].max()
+    assert float(err) <= 1e-4
+
+
 def test_wave_ops_selftest(gpu_ops):
     """The DPP reductions behind every dot product of the solver, on known data."""
     import torch
