@@ -228,7 +228,7 @@ def test_monte_carlo_full_size(gpu_ops):
     x0 = ops.transpose(ops.init(prm, lane(p0), lane(v0), lane(goal)))                         # (S, 9N) cold starts
     X0 = x0[:, None, :].repeat(1, Rr, 1)
     X0[:, 1:, 6 * N:] += torch.randn(S, Rr - 1, 3 * N, device=dev, generator=g)
-    rep = lambda a: a[:, None, :].repeat(1, Rr, 1).reshape(S * Rr, 3).contiguous()
+    rep = lambda a: a[:, None, :].repeat(1, Rr, 1).reshape(-1, 3).contiguous()
     out = ops.solve(prm, rep(p0), rep(v0), rep(goal), x0=X0.reshape(S * Rr, 9 * N).contiguous(), want_trajectory=False)
     info = ops.info_to_host(out["info"]).reshape(S, Rr)
     assert set(np.unique(info["status"])) <= {0, 1, 2}
