@@ -278,6 +278,22 @@ def main():
         np.savez_compressed(os.path.join(HERE, "mapper_spheres.npz"), **out)
         with open(os.path.join(HERE, "mapper_spheres.json"), "w") as f:
             json.dump(dict(cases=meta), f, indent=1)
+        # ---------------------------------------------- wire format: the reference's own serializer
+        from dart_planner.communication.secure_serializer import SecureSerializer
+        ser = SecureSerializer(secret_key="golden-secret-key", test_mode=True, message_ttl=10 ** 9)
+        payloads = [
+            {"status": "ok", "n": 3, "goal": np.array([5.0, 3.0, 2.0]), "nested": {"a": [1, 2.5, 3], "b": [[1.0, 2.0], [3.0, 4.0]]}},
+            {"trajectory": {"timestamps": np.arange(3) * 0.0025, "positions": np.arange(9.0).reshape(3, 3) / 7,
+                            "velocities": None, "thrusts": np.array([14.7, 14.6, 14.5])}},
+            [1, 2, 3],
+        ]
+        wire = []
+        for pl_ in payloads:
+            raw = ser.serialize(pl_)
+            back = ser.deserialize(raw)
+            wire.append(dict(raw=raw.decode("utf-8")))
+        with open(os.path.join(HERE, "wire_messages.json"), "w") as f:
+            json.dump(dict(secret="golden-secret-key", messages=wire), f, indent=1)
         print("wrote", os.listdir(HERE))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
