@@ -8,10 +8,33 @@
 // ("planner.py" in the comments), unit-stripped.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
 
 namespace se3mpc {
+
+// Lane bookkeeping shared by the one-trajectory-per-lane kernels (64-thread workgroups): blocks are taken
+// in XCD-contiguous order (blocks that share an XCD -- dispatch is round-robin over the 8 XCDs -- stream
+// adjacent columns: +5..10 % on the rollout kernel), rows are addressed through a buffer resource with a
+// 32-bit lane offset, and once-streamed operands use the nt cache policy.
+struct LaneIdx {
+  int b;
+  bool live;
+  unsigned voff;
+};
+template <typename R>
+__device__ __forceinline__ LaneIdx lane_index(int B) {
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  LaneIdx li;
+  const int b0 = blk * (int)blockDim.x + (int)threadIdx.x;
+  li.live = b0 < B;
+  li.b = li.live ? b0 : B - 1;
+  li.voff = (unsigned)li.b * (unsigned)sizeof(R);
+  return li;
+}
 
 // ------------------------------------------------------------------------------------------
 // a3 + a4: cold start (planner.py:329-359) and optional projection into the box (:378-402)
@@ -19,14 +42,17 @@ namespace se3mpc {
 template <typename R>
 __global__ void init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
                             const R* __restrict__ goal, int project, R* __restrict__ X) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  (void)b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
   const R denom = (R)(N - 1 > 1 ? N - 1 : 1);
   for (int a = 0; a < 3; ++a) {
-    const R p = p0[(size_t)a * ld + b];
-    const R v = v0[(size_t)a * ld + b];
-    const R g = q.has_goal ? goal[(size_t)a * ld + b] : p;
+    const R p = lane_ld<2>(lane_buf(p0), voff, (unsigned)(a) * rowb);
+    const R v = lane_ld<2>(lane_buf(v0), voff, (unsigned)(a) * rowb);
+    const R g = q.has_goal ? lane_ld<2>(lane_buf(goal), voff, (unsigned)(a) * rowb) : p;
     R prev = p;
     for (int i = 0; i < N; ++i) {
       R pi, vi;
@@ -51,9 +77,9 @@ __global__ void init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__
         vi = fmin(fmax(vi, -q.v_max), q.v_max);
         ti = (a == 2) ? fmin(fmax(ti, q.tz_lo), q.tz_hi) : ti;
       }
-      X[(size_t)(3 * i + a) * ld + b] = pi;
-      X[(size_t)(N3 + 3 * i + a) * ld + b] = vi;
-      X[(size_t)(2 * N3 + 3 * i + a) * ld + b] = ti;
+      lane_st<2>(lane_buf(X), voff, (unsigned)(3 * i + a) * rowb, (R)(pi));
+      lane_st<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * i + a) * rowb, (R)(vi));
+      lane_st<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * i + a) * rowb, (R)(ti));
     }
   }
 }
@@ -65,10 +91,10 @@ template <typename R>
 __global__ void __launch_bounds__(64)
 cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R* __restrict__ goal,
                  R* __restrict__ f, R* __restrict__ g) {
-  const int b0 = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = b0 < B;
-  const int b = live ? b0 : B - 1;                          // tail lanes shadow the last column (benign duplicate stores)
-  const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const LaneIdx li = lane_index<R>(B);
+  const bool live = li.live;
+  const int b = li.b;                                       // tail lanes shadow the last column (benign duplicate stores)
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
   const LaneBuf<R> xb = lane_buf(X), gb = lane_buf(g);
   R sp = 0, sv = 0, sa = 0, st = 0, sterm = 0;
@@ -107,22 +133,25 @@ cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R
 template <typename R>
 __global__ void dynamics_residual_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X,
                                          const R* __restrict__ p0, const R* __restrict__ v0, R* __restrict__ Rout) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  (void)b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
   for (int a = 0; a < 3; ++a) {
     const R grav = (a == 2) ? q.grav : (R)0;
-    R pk = X[(size_t)a * ld + b];
-    R vk = X[(size_t)(N3 + a) * ld + b];
-    Rout[(size_t)a * ld + b] = pk - p0[(size_t)a * ld + b];            // planner.py:439
-    Rout[(size_t)(3 + a) * ld + b] = vk - v0[(size_t)a * ld + b];      // planner.py:440
+    R pk = lane_ld<2>(lane_buf(X), voff, (unsigned)(a) * rowb);
+    R vk = lane_ld<2>(lane_buf(X), voff, (unsigned)(N3 + a) * rowb);
+    lane_st<2>(lane_buf(Rout), voff, (unsigned)(a) * rowb, (R)(pk - lane_ld<2>(lane_buf(p0), voff, (unsigned)(a) * rowb)));            // planner.py:439
+    lane_st<2>(lane_buf(Rout), voff, (unsigned)(3 + a) * rowb, (R)(vk - lane_ld<2>(lane_buf(v0), voff, (unsigned)(a) * rowb)));      // planner.py:440
     for (int k = 0; k + 1 < N; ++k) {
-      const R tk = X[(size_t)(2 * N3 + 3 * k + a) * ld + b];
-      const R pn = X[(size_t)(3 * (k + 1) + a) * ld + b];
-      const R vn = X[(size_t)(N3 + 3 * (k + 1) + a) * ld + b];
+      const R tk = lane_ld<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * k + a) * rowb);
+      const R pn = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * (k + 1) + a) * rowb);
+      const R vn = lane_ld<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * (k + 1) + a) * rowb);
       const R acc = tk / q.mass - grav;                                // planner.py:445-447
-      Rout[(size_t)(6 + 6 * k + a) * ld + b] = pn - pk - vk * q.dt - (R)0.5 * acc * (q.dt * q.dt);   // :450-455
-      Rout[(size_t)(6 + 6 * k + 3 + a) * ld + b] = vn - vk - acc * q.dt;                             // :459
+      lane_st<2>(lane_buf(Rout), voff, (unsigned)(6 + 6 * k + a) * rowb, (R)(pn - pk - vk * q.dt - (R)0.5 * acc * (q.dt * q.dt)));   // :450-455
+      lane_st<2>(lane_buf(Rout), voff, (unsigned)(6 + 6 * k + 3 + a) * rowb, (R)(vn - vk - acc * q.dt));                             // :459
       pk = pn; vk = vn;
     }
   }
@@ -144,18 +173,21 @@ __global__ void obstacle_residual_kernel(DevParams<R> q, int B, int ld, const R*
     sph[4 * i + 3] = s * s;
   }
   __syncthreads();
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  (void)b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N;
   R mn = INFINITY, vs = 0;
   for (int k = 0; k < N; ++k) {
-    const R px = X[(size_t)(3 * k + 0) * ld + b];
-    const R py = X[(size_t)(3 * k + 1) * ld + b];
-    const R pz = X[(size_t)(3 * k + 2) * ld + b];
+    const R px = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * k + 0) * rowb);
+    const R py = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * k + 1) * rowb);
+    const R pz = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * k + 2) * rowb);
     for (int j = 0; j < K; ++j) {
       const R dx = px - sph[4 * j + 0], dy = py - sph[4 * j + 1], dz = pz - sph[4 * j + 2];
       const R c = (dx * dx + dy * dy + dz * dz) - sph[4 * j + 3];     // planner.py:508-512
-      if (C != nullptr) C[(size_t)(k * K + j) * ld + b] = c;
+      if (C != nullptr) lane_st<2>(lane_buf(C), voff, (unsigned)(k * K + j) * rowb, (R)(c));
       mn = fmin(mn, c);
       vs += fmax((R)0, -c);
     }
@@ -169,21 +201,24 @@ __global__ void obstacle_residual_kernel(DevParams<R> q, int B, int ld, const R*
 // ------------------------------------------------------------------------------------------
 template <typename R>
 __global__ void physical_constraints_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, R* __restrict__ C) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  (void)b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
   for (int k = 0; k < N; ++k) {
     R v2 = 0, a2 = 0, t2 = 0;
     for (int a = 0; a < 3; ++a) {
-      const R v = X[(size_t)(N3 + 3 * k + a) * ld + b];
-      const R t = X[(size_t)(2 * N3 + 3 * k + a) * ld + b];
+      const R v = lane_ld<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * k + a) * rowb);
+      const R t = lane_ld<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * k + a) * rowb);
       const R acc = t / q.mass - ((a == 2) ? q.grav : (R)0);
       v2 += v * v; a2 += acc * acc; t2 += t * t;
     }
-    C[(size_t)k * ld + b] = q.v_max2 - v2;                             // planner.py:479-481
-    C[(size_t)(N + k) * ld + b] = q.a_max2 - a2;                       // planner.py:484-489
-    C[(size_t)(2 * N + 2 * k) * ld + b] = q.t_max2 - t2;               // planner.py:494
-    C[(size_t)(2 * N + 2 * k + 1) * ld + b] = t2 - q.t_min2;           // planner.py:495
+    lane_st<2>(lane_buf(C), voff, (unsigned)(k) * rowb, (R)(q.v_max2 - v2));                             // planner.py:479-481
+    lane_st<2>(lane_buf(C), voff, (unsigned)(N + k) * rowb, (R)(q.a_max2 - a2));                       // planner.py:484-489
+    lane_st<2>(lane_buf(C), voff, (unsigned)(2 * N + 2 * k) * rowb, (R)(q.t_max2 - t2));               // planner.py:494
+    lane_st<2>(lane_buf(C), voff, (unsigned)(2 * N + 2 * k + 1) * rowb, (R)(t2 - q.t_min2));           // planner.py:495
   }
 }
 
@@ -236,15 +271,18 @@ __device__ __forceinline__ void attitude_step(const R t[3], R inv_dt, AttitudeSt
 template <typename R>
 __global__ void extract_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ T, R* __restrict__ acc,
                                R* __restrict__ att, R* __restrict__ rates, R* __restrict__ thrust) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  (void)b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N;
   AttitudeState<R> prev;
   prev.valid = false;
   for (int i = 0; i < 3; ++i) prev.b1[i] = prev.b2[i] = prev.b3[i] = (R)0;
   for (int k = 0; k < N; ++k) {
     R t[3];
-    for (int a = 0; a < 3; ++a) t[a] = T[(size_t)(3 * k + a) * ld + b];
+    for (int a = 0; a < 3; ++a) t[a] = lane_ld<2>(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
     R at[3], rt[3], mag;
     attitude_step<R>(t, q.inv_dt, prev, at, rt, mag);
     for (int a = 0; a < 3; ++a) {
@@ -253,7 +291,7 @@ __global__ void extract_kernel(DevParams<R> q, int B, int ld, const R* __restric
       if (att != nullptr) att[r] = at[a];
       if (rates != nullptr) rates[r] = rt[a];
     }
-    if (thrust != nullptr) thrust[(size_t)k * ld + b] = mag;                      // planner.py:601
+    if (thrust != nullptr) lane_st<2>(lane_buf(thrust), voff, (unsigned)(k) * rowb, (R)(mag));                      // planner.py:601
   }
 }
 
@@ -552,17 +590,20 @@ rollout_lds_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, cons
 template <typename R>
 __global__ void is_plan_valid_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ P, const R* __restrict__ V,
                                      int32_t* __restrict__ valid) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  (void)b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N;
   bool ok = true;
   for (int k = 0; k < N; ++k) {
     for (int a = 0; a < 3; ++a) {
-      const R x = P[(size_t)(3 * k + a) * ld + b];
+      const R x = lane_ld<2>(lane_buf(P), voff, (unsigned)(3 * k + a) * rowb);
       if (isnan(x) || isinf(x)) ok = false;                            // planner.py:724
       if (a == 2 && x < (R)0.1) ok = false;                            // planner.py:728
       if (V != nullptr) {
-        const R v = V[(size_t)(3 * k + a) * ld + b];
+        const R v = lane_ld<2>(lane_buf(V), voff, (unsigned)(3 * k + a) * rowb);
         if (fabs(v) > (R)20.0) ok = false;                             // planner.py:734
       }
     }
@@ -687,11 +728,14 @@ transpose_kernel(int rows, int cols, const R* __restrict__ in, int ld_in, R* __r
 // ------------------------------------------------------------------------------------------
 // host side: validation + launch
 // ------------------------------------------------------------------------------------------
-static inline int check_lane_args(const se3mpc_params* p, int B, int ld) {
+// `rows` = the tallest lane-layout operand of the call: buffer offsets (row * ld * sizeof) must stay 32-bit
+static inline int check_lane_args(const se3mpc_params* p, int B, int ld, long long rows = 0, size_t elem = 8) {
   if (p == nullptr) return SE3MPC_ERR_NULL;
   const int rc = check_params_impl(p);
   if (rc != SE3MPC_OK) return rc;
   if (B < 0 || ld < B || ld > (1 << 28)) return SE3MPC_ERR_SHAPE;   // lane byte offsets stay 32-bit
+  if (rows == 0) rows = 9LL * p->horizon;
+  if ((unsigned long long)rows * (unsigned long long)ld * elem >= (1ull << 32)) return SE3MPC_ERR_SHAPE;
   return SE3MPC_OK;
 }
 
@@ -736,9 +780,9 @@ int dynamics_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, co
 template <typename R>
 int obstacle_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* spheres, int K, R* C, R* cmin,
                            R* viol, void* stream) {
-  int rc = check_lane_args(p, B, ld);
-  if (rc) return rc;
   if (K < 0 || K > SE3MPC_MAX_SPHERES) return SE3MPC_ERR_SHAPE;
+  int rc = check_lane_args(p, B, ld, p ? std::max(9LL * p->horizon, (long long)p->horizon * K) : 0, sizeof(R));
+  if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || (K > 0 && !spheres)) return SE3MPC_ERR_NULL;
   hipLaunchKernelGGL(obstacle_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
