@@ -375,11 +375,11 @@ __device__ __forceinline__ R axis_cost(const DevParams<R>& q, const RolloutSums<
 
 // One axis of one trajectory with exact-N register arrays.  Loads of all N thrust rows are issued
 // back to back (N independent HBM requests in flight per lane) before the first use.
-template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0>
+template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0, bool TILE = false>
 __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
-                                              R* __restrict__ Vout) {
+                                              R* __restrict__ Vout, R* __restrict__ ptile = nullptr) {
   R t[N], es[N], vs[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
@@ -395,6 +395,7 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
     const R dev = t[k] - c.hov;
     const R e = p - c.gl;
     es[k] = e; vs[k] = v;
+    if (TILE) ptile[k * kWave] = p;                        // per-step position tile in LDS (obstacle fusion)
     if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
     s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
     if (STATES) {
@@ -423,11 +424,11 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
 
 // Any N, O(1) registers: the reverse sweep re-reads T_k (L2) and walks the states backwards
 // through the inverted recurrence instead of storing them.
-template <typename R, bool GRAD, bool STATES, int STAUX = 0>
+template <typename R, bool GRAD, bool STATES, int STAUX = 0, bool TILE = false>
 __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
-                                              R* __restrict__ Vout) {
+                                              R* __restrict__ Vout, R* __restrict__ ptile = nullptr) {
   const int N = q.N;
   const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
   R p = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
@@ -440,6 +441,7 @@ __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsi
     const R acc = tk * q.inv_mass - c.grav;
     const R dev = tk - c.hov;
     const R e = p - c.gl;
+    if (TILE) ptile[k * kWave] = p;
     if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
     s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
     if (STATES) {
@@ -519,6 +521,65 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
     }
     rollout_epilogue<R>(live, b, total, cost, key != nullptr ? key + blk : nullptr, index_base);
   }
+}
+
+// Rollout fused with the sphere-obstacle residuals of planner.py:499-514 on the ROLLED-OUT positions
+// (BASELINE.json config 3: horizon 50, K = 16 spheres from the mapper).  The forward sweep of each axis
+// wavefront stages its positions as a per-step tile in LDS ([axis][k][lane], bank = lane: conflict free);
+// after the barrier the three wavefronts split the steps (k = w, w+3, ...) and evaluate
+// |P_k - c_j|^2 - (r_j + margin)^2 against the LDS-resident sphere table, keeping the minimum residual and
+// the summed violation per trajectory.  Neither the states nor the N*K residuals ever touch HBM:
+// 4*(6N+12) B per rollout instead of 4*(6N+10) + 4*(3N) written + 4*(3N) re-read for the unfused pair.
+template <typename R, int N, bool REG, bool GRAD>
+__global__ void __launch_bounds__(192)
+rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+                         const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
+                         R* __restrict__ gradT, const R* __restrict__ spheres, int K, R* __restrict__ cmin,
+                         R* __restrict__ viol, unsigned long long* __restrict__ key, uint32_t index_base) {
+  HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]
+  R* sph = tile + (size_t)3 * q.N * kWave;                   // [K][4] = (cx, cy, cz, (r + margin)^2)
+  R* part = sph + (size_t)4 * K;                             // [3][3][64]: cost, min residual, violation per axis wave
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    sph[4 * i + 0] = spheres[4 * i + 0]; sph[4 * i + 1] = spheres[4 * i + 1]; sph[4 * i + 2] = spheres[4 * i + 2];
+    const R sm = spheres[4 * i + 3] + q.margin;
+    sph[4 * i + 3] = sm * sm;
+  }
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int b0 = blk * kWave + lane;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;
+  const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
+  const int Nn = q.N;
+  R* my_tile = tile + (size_t)a * Nn * kWave + lane;
+  R c;
+  if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, false, 2, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
+  else c = rollout_axis_rev<R, GRAD, false, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
+  part[(0 * 3 + a) * kWave + lane] = c;
+  __syncthreads();
+  R mn = INFINITY, vs = (R)0;
+  for (int k = a; k < Nn; k += 3) {
+    const R px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
+            pz = tile[((size_t)2 * Nn + k) * kWave + lane];
+    for (int j = 0; j < K; ++j) {
+      const R dx = px - sph[4 * j + 0], dy = py - sph[4 * j + 1], dz = pz - sph[4 * j + 2];
+      const R cj = (dx * dx + dy * dy + dz * dz) - sph[4 * j + 3];
+      mn = fmin(mn, cj);
+      vs += fmax((R)0, -cj);
+    }
+  }
+  part[(1 * 3 + a) * kWave + lane] = mn;
+  part[(2 * 3 + a) * kWave + lane] = vs;
+  __syncthreads();
+  const R total = part[0 * kWave + lane] + part[1 * kWave + lane] + part[2 * kWave + lane];
+  if (live && a == 0) {
+    if (cmin != nullptr) cmin[b] = fmin(part[3 * kWave + lane], fmin(part[4 * kWave + lane], part[5 * kWave + lane]));
+    if (viol != nullptr) viol[b] = part[6 * kWave + lane] + part[7 * kWave + lane] + part[8 * kWave + lane];
+  }
+  rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
 }
 
 template <typename R, bool GRAD, bool STATES>
@@ -893,6 +954,37 @@ int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
 }
 
 template <typename R>
+int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal, const R* T,
+                           R* cost, R* gradT, const R* spheres, int K, R* cmin, R* viol, uint64_t* key64, uint32_t index_base,
+                           void* stream) {
+  if (K < 0 || K > SE3MPC_MAX_SPHERES) return SE3MPC_ERR_SHAPE;
+  int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));
+  if (rc) return rc;
+  if (B == 0) return SE3MPC_OK;
+  if (!p0 || !v0 || !T || !cost || (p->has_goal && !goal) || (K > 0 && !spheres)) return SE3MPC_ERR_NULL;
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
+  const DevParams<R> q = make_dev_params<R>(*p);
+  const int N = p->horizon, nblk = grid_for(B, kWave);
+  const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * K + (size_t)9 * kWave) * sizeof(R);
+  hipStream_t s = (hipStream_t)stream;
+  const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
+#define SE3MPC_OBST(NN, REG, GRAD)                                                                                    \
+  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD>), dim3(nblk), dim3(192), lds, s, q, B, ld, p0, v0, goal, \
+                     T, cost, gradT, spheres, K, cmin, viol, key, index_base)
+#define SE3MPC_OBST_N(GRAD)                                                     \
+  if (!has_reg) SE3MPC_OBST(0, false, GRAD);                                    \
+  else if (N == 6) SE3MPC_OBST(6, true, GRAD);                                  \
+  else if (N == 20) SE3MPC_OBST(20, true, GRAD);                                \
+  else if constexpr (sizeof(R) == 4) {                                          \
+    if (N == 30) SE3MPC_OBST(30, true, GRAD); else SE3MPC_OBST(50, true, GRAD); \
+  }
+  if (gradT != nullptr) { SE3MPC_OBST_N(true) } else { SE3MPC_OBST_N(false) }
+#undef SE3MPC_OBST_N
+#undef SE3MPC_OBST
+  return launch_status("se3mpc_rollout_obstacles");
+}
+
+template <typename R>
 int is_plan_valid_impl(const se3mpc_params* p, int B, int ld, const R* P, const R* V, int32_t* valid, void* stream) {
   int rc = check_lane_args(p, B, ld);
   if (rc) return rc;
@@ -979,6 +1071,13 @@ using namespace se3mpc;
                                                         uint64_t* keys, uint32_t index_base, void* stream) {             \
     return rollout_cost_grad_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, (R*)nullptr, (R*)nullptr, keys, index_base, \
                                      nbatch, stream);                                                                    \
+  }                                                                                                                      \
+  extern "C" int se3mpc_rollout_obstacles_##SUF(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0,          \
+                                                const R* goal, const R* T, R* cost, R* gradT, const R* spheres, int K,   \
+                                                R* cmin, R* viol, uint64_t* wave_keys, uint32_t index_base,              \
+                                                void* stream) {                                                          \
+    return rollout_obstacles_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, spheres, K, cmin, viol, wave_keys,          \
+                                     index_base, stream);                                                                \
   }                                                                                                                      \
   extern "C" int se3mpc_is_plan_valid_##SUF(const se3mpc_params* p, int B, int ld, const R* P, const R* V,                \
                                             int32_t* valid, void* stream) {                                              \

@@ -230,6 +230,28 @@ class Ops:
                       self.be.ptr(gradT), self.be.ptr(wave_keys), int(index_base), self.be.stream(), params=params)
         return cost, gradT
 
+    def rollout_obstacles(self, params: Params, p0, v0, goal, T, spheres, want_grad: bool = True, B: Optional[int] = None,
+                          wave_keys=None, index_base: int = 0):
+        """Rollout + cost (+ gradient) fused with the sphere-obstacle residuals of the rolled-out positions.
+        -> (cost (ld,), gradT (3N, ld) | None, cmin (ld,), viol (ld,))."""
+        N = params.horizon
+        self._lane(p0, 3, "p0"); self._lane(v0, 3, "v0"); self._lane(T, 3 * N, "T")
+        if params.has_goal:
+            self._lane(goal, 3, "goal")
+        suf = self._same(T, p0, v0, goal if params.has_goal else None)
+        self.be.check(spheres, "spheres")
+        if spheres.ndim != 2 or spheres.shape[1] != 4 or spheres.shape[0] > SE3MPC_MAX_SPHERES or self.be.suffix(spheres) != suf:
+            raise ValueError(f"spheres: expected (K<={SE3MPC_MAX_SPHERES}, 4) {suf}, got {tuple(spheres.shape)}")
+        ld = T.shape[1]
+        cost = self.be.empty((ld,), suf)
+        gradT = self.be.empty((3 * N, ld), suf) if want_grad else None
+        cmin, viol = self.be.empty((ld,), suf), self.be.empty((ld,), suf)
+        self.lib.call("rollout_obstacles", suf, self._B(ld, B), ld, self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost), self.be.ptr(gradT),
+                      self.be.ptr(spheres), spheres.shape[0], self.be.ptr(cmin), self.be.ptr(viol), self.be.ptr(wave_keys),
+                      int(index_base), self.be.stream(), params=params)
+        return cost, gradT, cmin, viol
+
     def is_plan_valid(self, params: Params, P, V=None, B: Optional[int] = None):
         """a16: -> int32 (ld,)."""
         N = params.horizon

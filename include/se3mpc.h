@@ -189,6 +189,17 @@ int se3mpc_rollout_cost_grad_batched_f64(const se3mpc_params* p, int B, int ld, 
                                          const double* v0, const double* goal, const double* T, double* cost,
                                          double* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream);
 
+/* The same rollout fused with the sphere-obstacle residuals of planner.py:499-514 evaluated on the ROLLED-OUT
+ * positions (BASELINE.json config 3): per-step positions staged in LDS, sphere table in LDS, cmin[b] = min over
+ * (k, j) of |P_k - c_j|^2 - (r_j + margin)^2 and viol[b] = sum of max(0, -residual); neither the states nor the
+ * N*K residuals are written to HBM.  spheres: [K][4]; cmin, viol: [B] (either may be NULL); gradT may be NULL. */
+int se3mpc_rollout_obstacles_f32(const se3mpc_params* p, int B, int ld, const float* p0, const float* v0,
+                                 const float* goal, const float* T, float* cost, float* gradT, const float* spheres,
+                                 int K, float* cmin, float* viol, uint64_t* wave_keys, uint32_t index_base, void* stream);
+int se3mpc_rollout_obstacles_f64(const se3mpc_params* p, int B, int ld, const double* p0, const double* v0,
+                                 const double* goal, const double* T, double* cost, double* gradT, const double* spheres,
+                                 int K, double* cmin, double* viol, uint64_t* wave_keys, uint32_t index_base, void* stream);
+
 /* keys_out[i] = min over wave_keys[i][0..per_batch) for i < nbatch (one small workgroup per batch). */
 int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uint64_t* keys_out, void* stream);
 

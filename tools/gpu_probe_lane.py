@@ -36,3 +36,16 @@ bench("is_plan_valid", lambda: ops.is_plan_valid(prm, X[:3 * N], X[3 * N:6 * N])
 bench("transpose 9N x B", lambda: ops.transpose(X), f4 * 18 * N)
 cost = torch.rand(B, device=dev)
 bench("argmin", lambda: ops.argmin(cost), f4)
+# config 3: horizon 50, K = 16 spheres: fused rollout+obstacles vs rollout(states) followed by obstacle reduce
+N3 = 50; prm3 = Params.reference_defaults(horizon=N3)
+for B3 in (8192, 1 << 20):
+    T3 = torch.randn(3 * N3, B3, device=dev, generator=g) * 2; T3[2::3] += 14.715
+    q0 = torch.rand(3, B3, device=dev, generator=g) * 40 - 20; w0 = torch.rand(3, B3, device=dev, generator=g) * 10 - 5
+    gl = torch.rand(3, B3, device=dev, generator=g) * 40 - 20
+    bytes3 = 4 * B3 * (6 * N3 + 12)
+    bench(f"cfg3 fused B={B3}", lambda: ops.rollout_obstacles(prm3, q0, w0, gl, T3, sph), bytes3)
+    def unfused():
+        c, gT, P, V = ops.rollout_cost_grad(prm3, q0, w0, gl, T3, want_states=True)
+        X = torch.cat([P, V, T3], 0)
+        return ops.obstacle_residual(prm3, X, sph, materialize=False)
+    bench(f"cfg3 unfused B={B3}", unfused, bytes3)
