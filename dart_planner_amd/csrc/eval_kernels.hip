@@ -561,29 +561,14 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
   part[(0 * 3 + a) * kWave + lane] = c;
   __syncthreads();
   R mn = INFINITY, vs = (R)0;
-  // four steps per pass: 12 positions in registers, each sphere read once (one 16-byte LDS broadcast) per pass
-  struct alignas(4 * sizeof(R)) Sph { R x, y, z, s2; };
-  const Sph* sp4 = reinterpret_cast<const Sph*>(sph);
-  for (int k0 = a; k0 < Nn; k0 += 12) {
-    R px[4], py[4], pz[4];
-    bool on[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + 3 * u;
-      on[u] = k < Nn;
-      const int kk = on[u] ? k : k0;
-      px[u] = tile[((size_t)0 * Nn + kk) * kWave + lane];
-      py[u] = tile[((size_t)1 * Nn + kk) * kWave + lane];
-      pz[u] = tile[((size_t)2 * Nn + kk) * kWave + lane];
-    }
+  for (int k = a; k < Nn; k += 3) {
+    const R px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
+            pz = tile[((size_t)2 * Nn + k) * kWave + lane];
     for (int j = 0; j < K; ++j) {
-      const Sph sj = sp4[j];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const R dx = px[u] - sj.x, dy = py[u] - sj.y, dz = pz[u] - sj.z;
-        const R cj = (dx * dx + dy * dy + dz * dz) - sj.s2;
-        if (on[u]) { mn = fmin(mn, cj); vs += fmax((R)0, -cj); }
-      }
+      const R dx = px - sph[4 * j + 0], dy = py - sph[4 * j + 1], dz = pz - sph[4 * j + 2];
+      const R cj = (dx * dx + dy * dy + dz * dz) - sph[4 * j + 3];
+      mn = fmin(mn, cj);
+      vs += fmax((R)0, -cj);
     }
   }
   part[(1 * 3 + a) * kWave + lane] = mn;
