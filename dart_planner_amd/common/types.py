@@ -1,8 +1,8 @@
 """Boundary dataclasses of the Planner->Controller contract.
 
-Same field names, order and defaults as the reference (src/dart_planner/common/types.py:30-140);
-fields hold SI magnitudes as float64 ndarrays (see common/units.py) instead of pint Quantities.
-"""
+Field names, order and defaults follow the reference (src/dart_planner/common/types.py:30-140) so callers can
+construct and read them the same way; values are SI magnitudes held as float64 ndarrays (common/units.py)
+instead of pint Quantities."""
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -11,36 +11,47 @@ import numpy as np
 from .units import ensure_units
 
 
+def _vec3():
+    return field(default_factory=lambda: np.zeros(3))
+
+
+def _to_si(obj, table) -> None:
+    """Normalise the listed attributes of a dataclass instance to SI magnitudes (accepts numbers, arrays and
+    pint-like quantities)."""
+    owner = type(obj).__name__
+    for name, unit in table:
+        setattr(obj, name, ensure_units(getattr(obj, name), unit, f"{owner}.{name}"))
+
+
+_STATE_UNITS = (("position", "m"), ("velocity", "m/s"), ("attitude", "rad"), ("angular_velocity", "rad/s"))
+
+
 @dataclass
 class FastDroneState:
-    """reference types.py:30-56"""
+    """Unit-free state for high-rate loops (reference :30-56)."""
     timestamp: float
-    position: np.ndarray = field(default_factory=lambda: np.zeros(3))
-    velocity: np.ndarray = field(default_factory=lambda: np.zeros(3))
-    attitude: np.ndarray = field(default_factory=lambda: np.zeros(3))
-    angular_velocity: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    position: np.ndarray = _vec3()
+    velocity: np.ndarray = _vec3()
+    attitude: np.ndarray = _vec3()
+    angular_velocity: np.ndarray = _vec3()
 
     @classmethod
     def from_drone_state(cls, state: "DroneState") -> "FastDroneState":
-        return cls(state.timestamp, np.array(state.position), np.array(state.velocity), np.array(state.attitude),
-                   np.array(state.angular_velocity))
+        return cls(state.timestamp, *(np.array(getattr(state, n), dtype=float) for n, _ in _STATE_UNITS))
 
 
 @dataclass
 class DroneState:
-    """reference types.py:63-101"""
+    """Full vehicle state at one instant (reference :63-101)."""
     timestamp: float
-    position: np.ndarray = field(default_factory=lambda: np.zeros(3))
-    velocity: np.ndarray = field(default_factory=lambda: np.zeros(3))
-    attitude: np.ndarray = field(default_factory=lambda: np.zeros(3))
-    angular_velocity: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    position: np.ndarray = _vec3()
+    velocity: np.ndarray = _vec3()
+    attitude: np.ndarray = _vec3()            # roll, pitch, yaw
+    angular_velocity: np.ndarray = _vec3()
     motor_rpms: Optional[np.ndarray] = field(default_factory=lambda: np.zeros(4))
 
     def __post_init__(self):
-        self.position = ensure_units(self.position, "m", "DroneState.position")
-        self.velocity = ensure_units(self.velocity, "m/s", "DroneState.velocity")
-        self.attitude = ensure_units(self.attitude, "rad", "DroneState.attitude")
-        self.angular_velocity = ensure_units(self.angular_velocity, "rad/s", "DroneState.angular_velocity")
+        _to_si(self, _STATE_UNITS)
 
     def to_fast_state(self) -> FastDroneState:
         return FastDroneState.from_drone_state(self)
@@ -48,34 +59,34 @@ class DroneState:
 
 @dataclass
 class ControlCommand:
-    """reference types.py:103-113: thrust [N], torque [N m]."""
+    """Collective thrust [N] and body torque [N m] (reference :103-113)."""
     thrust: float = 0.0
-    torque: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    torque: np.ndarray = _vec3()
 
     def __post_init__(self):
-        self.thrust = float(ensure_units(self.thrust, "N", "ControlCommand.thrust"))
-        self.torque = ensure_units(self.torque, "N*m", "ControlCommand.torque")
+        _to_si(self, (("thrust", "N"), ("torque", "N*m")))
+        self.thrust = float(self.thrust)
 
 
 @dataclass
 class BodyRateCommand:
-    """reference types.py:115-125: normalised thrust in [0, 1], body rates [rad/s]."""
+    """Normalised thrust in [0, 1] and body rates [rad/s] (reference :115-125)."""
     thrust: float
-    body_rates: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    body_rates: np.ndarray = _vec3()
 
     def __post_init__(self):
-        self.body_rates = ensure_units(self.body_rates, "rad/s", "BodyRateCommand.body_rates")
+        _to_si(self, (("body_rates", "rad/s"),))
 
 
 @dataclass
 class Trajectory:
-    """reference types.py:127-140"""
+    """Time-indexed plan handed from planner to controller (reference :127-140)."""
     timestamps: np.ndarray
     positions: np.ndarray
     velocities: Optional[np.ndarray] = None
     accelerations: Optional[np.ndarray] = None
-    attitudes: Optional[np.ndarray] = None
+    attitudes: Optional[np.ndarray] = None     # roll, pitch, yaw
     body_rates: Optional[np.ndarray] = None
-    thrusts: Optional[np.ndarray] = None
+    thrusts: Optional[np.ndarray] = None       # |thrust vector| per step
     yaws: Optional[np.ndarray] = None
     yaw_rates: Optional[np.ndarray] = None
