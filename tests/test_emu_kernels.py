@@ -49,6 +49,13 @@ def test_solver_reproduces_reference_solves(emu_ops, golden_solve, dt):
     assert worst <= (1e-4 if dt == np.float32 else 1e-9)
 
 
+def test_batched_solve_matches_scipy_odd_horizons(emu_ops):
+    # horizons that are not template instantiations (J = 2, 5 with padding lanes), a few problems each
+    for N, B in ((13, 6), (33, 4)):
+        worst, mism = pc.check_solver_vs_oracle(harness(emu_ops, np.float64), N, B, seed=N)
+        assert mism == 0.0 and worst <= 1e-9
+
+
 def test_solver_extraction_and_cold_start(emu_ops):
     pc.check_solver_extraction(harness(emu_ops, np.float64), 6, 4)
     pc.check_solver_extraction(harness(emu_ops, np.float32), 20, 3)

@@ -55,7 +55,7 @@ def test_solver_extraction_and_cold_start(gpu_ops, dt, N):
     pc.check_solver_extraction(harness(gpu_ops, dt), N, 37)
 
 
-@pytest.mark.parametrize("N,B", [(6, 256), (20, 128), (30, 256), (50, 96)])
+@pytest.mark.parametrize("N,B", [(6, 256), (20, 128), (30, 256), (50, 96), (64, 48), (13, 100), (33, 64), (1, 40), (2, 40)])
 def test_batched_solve_matches_scipy_problem_by_problem(gpu_ops, N, B):
     """Config 1/2 of BASELINE.json: random (state, goal) pairs, reference options."""
     for dt, tol in ((np.float64, 1e-9), (np.float32, 1e-4)):
