@@ -375,15 +375,19 @@ __device__ __forceinline__ R axis_cost(const DevParams<R>& q, const RolloutSums<
 
 // One axis of one trajectory with exact-N register arrays.  Loads of all N thrust rows are issued
 // back to back (N independent HBM requests in flight per lane) before the first use.
-template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0, bool TILE = false>
+template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0, bool TILE = false, bool EXACT = true>
 __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
                                               R* __restrict__ Vout, R* __restrict__ ptile = nullptr) {
+  // N is the compile-time register bound.  EXACT: the horizon equals N (no guards).  !EXACT: the horizon is
+  // q.N <= N and every step is guarded by a wave-uniform (scalar) branch -- the bucketed fallback
+  // (N in {16, 32, 64}) that keeps exact states and all loads in flight for any horizon.
+  const int Nn = EXACT ? N : q.N;
   R t[N], es[N], vs[N];
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    t[k] = lane_ld<LDAUX>(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
+    if (EXACT || k < Nn) t[k] = lane_ld<LDAUX>(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
   }
   const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
   R p = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
@@ -391,32 +395,40 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
   RolloutSums<R> s = {0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < N; ++k) {
-    const R acc = t[k] * q.inv_mass - c.grav;
-    const R dev = t[k] - c.hov;
-    const R e = p - c.gl;
-    es[k] = e; vs[k] = v;
-    if (TILE) ptile[k * kWave] = p;                        // per-step position tile in LDS (obstacle fusion)
-    if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
-    s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
-    if (STATES) {
-      lane_st(lane_buf(Pout), voff, (unsigned)(3 * k + a) * rowb, p);
-      lane_st(lane_buf(Vout), voff, (unsigned)(3 * k + a) * rowb, v);
+    if (EXACT || k < Nn) {
+      const R acc = t[k] * q.inv_mass - c.grav;
+      const R dev = t[k] - c.hov;
+      const R e = p - c.gl;
+      es[k] = e; vs[k] = v;
+      if (TILE) ptile[k * kWave] = p;                        // per-step position tile in LDS (obstacle fusion)
+      if (k == Nn - 1) s.sterm = e * e; else s.sp += e * e;
+      s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      if (STATES) {
+        lane_st(lane_buf(Pout), voff, (unsigned)(3 * k + a) * rowb, p);
+        lane_st(lane_buf(Vout), voff, (unsigned)(3 * k + a) * rowb, v);
+      }
+      p = p + v * q.dt + q.half_dt2 * acc;                   // planner.py:450-455 solved for P_{k+1}
+      v = v + acc * q.dt;                                    // planner.py:459 solved for V_{k+1}
     }
-    p = p + v * q.dt + q.half_dt2 * acc;                   // planner.py:450-455 solved for P_{k+1}
-    v = v + acc * q.dt;                                    // planner.py:459 solved for V_{k+1}
   }
   s.sp += s.sterm;
   if (GRAD) {
-    R lamP = c.two_wp * ((R)1 + q.term) * es[N - 1];
-    R lamV = c.two_wv * vs[N - 1];
-    lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, c.c_aa * (t[N - 1] * q.inv_mass - c.grav) + c.c_tt * (t[N - 1] - c.hov));
+    R lamP = (R)0, lamV = (R)0;
 #pragma unroll
-    for (int k = N - 2; k >= 0; --k) {
-      const R acc = t[k] * q.inv_mass - c.grav;
-      const R dev = t[k] - c.hov;
-      lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
-      lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
-      lamP = c.two_wp * es[k] + lamP;
+    for (int k = N - 1; k >= 0; --k) {
+      if (EXACT || k < Nn) {
+        const R acc = t[k] * q.inv_mass - c.grav;
+        const R dev = t[k] - c.hov;
+        if (k == Nn - 1) {
+          lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev);
+          lamP = c.two_wp * ((R)1 + q.term) * es[k];
+          lamV = c.two_wv * vs[k];
+        } else {
+          lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV);
+          lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
+          lamP = c.two_wp * es[k] + lamP;
+        }
+      }
     }
   }
   return axis_cost(q, s);
@@ -478,7 +490,8 @@ __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsi
 // epilogue and wavefront 0 commits it.  !SPLIT: one wavefront per 64 trajectories loops the axes.
 // blockIdx.y = batch index of a multi-batch launch: consecutive batches are consecutive [rows][ld]
 // blocks of every operand (keys: one word per batch).  FLAGS: bit 0 nt loads of T, bit 1 nt stores of
-// the gradient, bit 2 XCD-contiguous block order (blocks that share an XCD stream adjacent columns).
+// the gradient, bit 2 XCD-contiguous block order (blocks that share an XCD stream adjacent columns), bit 3
+// N is a register bucket (horizon q.N <= N, guarded steps) instead of the exact horizon.
 template <typename R, int N, bool REG, bool SPLIT, bool GRAD, bool STATES, int FLAGS = 7>
 __global__ void __launch_bounds__(SPLIT ? 192 : 64)
 rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
@@ -506,7 +519,7 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
     __shared__ R part[3][kWave];
     const int a = wave_uniform((int)(threadIdx.x / kWave));   // wave index -> SGPR, so row bases stay scalar
     R c;
-    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, STATES, (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, STATES, (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0, false, !(FLAGS & 8)>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
     else c = rollout_axis_rev<R, GRAD, STATES, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
     part[a][lane] = c;
     __syncthreads();
@@ -516,7 +529,7 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
     total = (R)0;
 #pragma unroll 1
     for (int a = 0; a < 3; ++a) {
-      if constexpr (REG) total += rollout_axis_reg<R, N, GRAD, STATES, (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
+      if constexpr (REG) total += rollout_axis_reg<R, N, GRAD, STATES, (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0, false, !(FLAGS & 8)>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
       else total += rollout_axis_rev<R, GRAD, STATES, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
     }
     rollout_epilogue<R>(live, b, total, cost, key != nullptr ? key + blk : nullptr, index_base);
@@ -873,7 +886,7 @@ int extract_impl(const se3mpc_params* p, int B, int ld, const R* T, R* acc, R* a
   return launch_status("se3mpc_extract");
 }
 
-static int g_rollout_variant = 0;   // 0 auto, 1 REG split, 2 LDS, 3 REV split, 4 REG mono, 5 REV mono; +8*(FLAGS+1): explicit FLAGS (N = 30 f32 grad only)
+static int g_rollout_variant = 0;   // 0 auto, 1 REG split, 2 LDS, 3 REV split, 4 REG mono, 5 REV mono, 6 REG bucket; +8*(FLAGS+1): explicit FLAGS (N = 30 f32 grad only)
 
 template <typename R, bool GRAD, bool STATES>
 int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* p0, const R* v0, const R* goal,
@@ -886,8 +899,12 @@ int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* 
   const int N = p->horizon;
   // exact-N register kernels exist for the BASELINE horizons; f64 arrays spill beyond N = 20
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
-  if (variant == 0) variant = has_reg ? 1 : 3;
+  // any other horizon: register buckets of 16 / 32 / 64 steps (f64: 16 only, two VGPRs per value), else the
+  // reversible sweep
+  const bool has_bucket = sizeof(R) == 4 ? true : N <= 16;
+  if (variant == 0) variant = has_reg ? 1 : (has_bucket ? 6 : 3);
   if ((variant == 1 || variant == 4) && !has_reg) variant = (variant == 1) ? 3 : 5;
+  if (variant == 6 && !has_bucket) variant = 3;
 #define SE3MPC_LAUNCH(NN, REG, SPLIT)                                                                               \
   hipLaunchKernelGGL((rollout_kernel<R, NN, REG, SPLIT, GRAD, STATES>), dim3(nblk, nbatch), dim3(SPLIT ? 192 : 64), 0, \
                      s, q, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base)
@@ -916,6 +933,17 @@ int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* 
 #undef SE3MPC_FLAG_CASE
       return launch_status("se3mpc_rollout_cost_grad");
     }
+  }
+  if (variant == 6) {
+#define SE3MPC_BUCKET(NB)                                                                                           \
+  hipLaunchKernelGGL((rollout_kernel<R, NB, true, true, GRAD, STATES, 15>), dim3(nblk, nbatch), dim3(192), 0, s, q, B,  \
+                     ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base)
+    if (N <= 16) SE3MPC_BUCKET(16);
+    else if constexpr (sizeof(R) == 4) {
+      if (N <= 32) SE3MPC_BUCKET(32); else SE3MPC_BUCKET(64);
+    }
+#undef SE3MPC_BUCKET
+    return launch_status("se3mpc_rollout_cost_grad");
   }
   if (variant == 1) { SE3MPC_REG_SWITCH(true) }
   else if (variant == 4) { SE3MPC_REG_SWITCH(false) }
@@ -1105,7 +1133,7 @@ extern "C" int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int 
 }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant > 71 || (variant & 7) > 5) return SE3MPC_ERR_SHAPE;
+  if (variant < 0 || variant > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
   se3mpc::g_rollout_variant = variant;
   return SE3MPC_OK;
 }

@@ -33,7 +33,7 @@ def harness(ops, dt):
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (20, 257), (30, 1000), (50, 129), (64, 65), (7, 9), (33, 200)])
 def test_lane_kernels(gpu_ops, dt, N, B):
-    pc.check_lane_kernels(harness(gpu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5))
+    pc.check_lane_kernels(harness(gpu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5, 6))
 
 
 def test_lane_kernels_other_dt(gpu_ops):
