@@ -899,9 +899,10 @@ int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* 
   const int N = p->horizon;
   // exact-N register kernels exist for the BASELINE horizons; f64 arrays spill beyond N = 20
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
-  // any other horizon: register buckets of 16 / 32 / 64 steps (f64: 16 only, two VGPRs per value), else the
-  // reversible sweep
-  const bool has_bucket = sizeof(R) == 4 ? true : N <= 16;
+  // any other horizon (measured at B = 1 M, tools/gpu_probe_horizons.py): 17..32 steps -> a 32-step register bucket
+  // (guarded steps; 5.3-5.5 TB/s vs 4.5-4.7 for the reversible sweep); <= 16 or > 32 steps -> the reversible
+  // sweep (6.0-6.5 TB/s on short horizons; a 64-step bucket needs 256 VGPRs and drops to 2.2 TB/s).  f32 only.
+  const bool has_bucket = sizeof(R) == 4 && N > 16 && N <= 32;
   if (variant == 0) variant = has_reg ? 1 : (has_bucket ? 6 : 3);
   if ((variant == 1 || variant == 4) && !has_reg) variant = (variant == 1) ? 3 : 5;
   if (variant == 6 && !has_bucket) variant = 3;
@@ -938,10 +939,7 @@ int rollout_launch(const se3mpc_params* p, int variant, int B, int ld, const R* 
 #define SE3MPC_BUCKET(NB)                                                                                           \
   hipLaunchKernelGGL((rollout_kernel<R, NB, true, true, GRAD, STATES, 15>), dim3(nblk, nbatch), dim3(192), 0, s, q, B,  \
                      ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base)
-    if (N <= 16) SE3MPC_BUCKET(16);
-    else if constexpr (sizeof(R) == 4) {
-      if (N <= 32) SE3MPC_BUCKET(32); else SE3MPC_BUCKET(64);
-    }
+    if constexpr (sizeof(R) == 4) SE3MPC_BUCKET(32);
 #undef SE3MPC_BUCKET
     return launch_status("se3mpc_rollout_cost_grad");
   }

@@ -206,7 +206,8 @@ int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uin
 /* Tuning knob for measurements: which implementation of the rollout the entry point above
  * launches.  0 = auto (default), 1 = exact-N register arrays (N in {6,20,30,50}; falls back to
  * 3 otherwise), 2 = per-step state tiles staged in LDS, 3 = register-light reversible sweep, 4 / 5 = 1 / 3
- * with one wavefront looping over the three axes.  variant + 8 * (flags + 1) forces the memory-policy
+ * with one wavefront looping over the three axes, 6 = 32-step register bucket with guarded steps (f32, horizons 17..32;
+ * else 3).  variant + 8 * (flags + 1) forces the memory-policy
  * flags of the benchmarked instantiation (horizon 30, f32, gradient): bit 0 nt loads, bit 1 nt stores,
  * bit 2 XCD-contiguous block order; the default is all three (7).  All compute the same quantities
  * (DESIGN.md section 5). */

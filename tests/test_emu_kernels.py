@@ -29,7 +29,7 @@ def harness(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (30, 66), (7, 9)])
+@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (30, 66), (7, 9), (24, 65)])
 def test_lane_kernels(emu_ops, dt, N, B):
     # B = 70 / 66 leave a partial last wavefront (tail lanes); N = 7 takes the generic (non-template) path
     pc.check_lane_kernels(harness(emu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5, 6))
