@@ -31,7 +31,7 @@ def harness(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (20, 257), (30, 1000), (50, 129), (64, 65), (7, 9), (33, 200)])
+@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (20, 257), (30, 1000), (50, 129), (64, 65), (7, 9), (33, 200), (24, 130), (17, 64), (32, 100)])
 def test_lane_kernels(gpu_ops, dt, N, B):
     pc.check_lane_kernels(harness(gpu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5, 6))
 
