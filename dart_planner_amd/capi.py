@@ -60,11 +60,19 @@ class Params(C.Structure):
                 position_bound=100.0, max_velocity=10.0, max_acceleration=15.0, max_thrust=25.0, min_thrust=2.0,
                 max_tilt_angle=math.pi / 4, safety_margin=1.5, max_iterations=15, max_corrections=10,
                 max_linesearch=20, max_fun=15000, pgtol=0.05, ftol=0.5)
+        names = cls._field_names()
         for k, v in overrides.items():
-            if k not in dict(cls._fields_):
+            if k not in names:
                 raise AttributeError(f"se3mpc_params has no field {k!r}")
             setattr(p, k, v)
         return p
+
+    @classmethod
+    def _field_names(cls) -> frozenset:
+        names = cls.__dict__.get("_names")
+        if names is None:
+            names = cls._names = frozenset(n for n, _ in cls._fields_)
+        return names
 
     def copy(self, **overrides) -> "Params":
         q = Params()

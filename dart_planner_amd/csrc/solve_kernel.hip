@@ -925,7 +925,10 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   else if (Jneed <= 8) SE3MPC_SOLVE_CASE(8);   \
   else SE3MPC_SOLVE_CASE(9)
   constexpr int kFastPairs = 4;
-  const bool two_tier = info != nullptr && q.m > kFastPairs;    // the tiers talk through info[].task
+  // Two tiers buy occupancy (two resident solves per SIMD instead of one); up to one wavefront per SIMD of
+  // the chip (256 CUs x 4) there is nothing to buy, and a single launch with the full memory is quicker.
+  constexpr int kOneTierProblems = 1024;
+  const bool two_tier = info != nullptr && q.m > kFastPairs && B > kOneTierProblems;    // the tiers talk through info[].task
   q.mlds = two_tier ? kFastPairs : q.m;
   SE3MPC_SOLVE_LAUNCH();
   rc = launch_status("se3mpc_solve");

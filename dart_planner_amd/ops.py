@@ -56,6 +56,9 @@ class TorchBackend:
     def ptr(self, a) -> int:
         return 0 if a is None else a.data_ptr()
 
+    def is_host_mapped(self, a) -> bool:
+        return self.torch.is_tensor(a) and not a.is_cuda and a.is_pinned() and a.is_contiguous()
+
     def stream(self) -> int:
         return self.torch.cuda.current_stream(self.device).cuda_stream
 
@@ -333,13 +336,24 @@ class Ops:
                       self.be.ptr(rates), self.be.ptr(thrust), self.be.stream(), params=params)
         return dict(x=X, info=info, accelerations=acc, attitudes=att, body_rates=rates, thrusts=thrust)
 
-    def solve_packed(self, params: Params, inputs, x0=None, out=None):
+    def solve_packed(self, params: Params, inputs, x0=None, out=None, host_mapped=False, stream=None):
         """Latency-oriented form of :meth:`solve` for the planner: ONE device buffer in, ONE out.
         inputs: (3, B, 3) = stacked (p0, v0, goal) [goal ignored when has_goal == 0];
         out: uint8 buffer of :meth:`packed_size` bytes (allocated if None) laid out as
-        [X | acc | att | rates | thrust | info]; decode on the host with :meth:`unpack_solution`."""
+        [X | acc | att | rates | thrust | info]; decode on the host with :meth:`unpack_solution`.
+        host_mapped=True: `inputs`, `x0` and `out` are PINNED host tensors; the kernel reads and writes them in
+        place over the host link (hipHostMalloc memory is mapped into the device's address space under the
+        same address), which for a handful of problems beats two staged copies.  The caller synchronises the
+        stream before reading `out`."""
         N = params.horizon
-        self.be.check(inputs, "inputs")
+        if host_mapped:
+            for name, a in (("inputs", inputs), ("x0", x0), ("out", out)):
+                if a is None and name == "x0":
+                    continue
+                if a is None or not self.be.is_host_mapped(a):
+                    raise TypeError(f"{name}: host_mapped=True needs a pinned, contiguous host tensor")
+        else:
+            self.be.check(inputs, "inputs")
         if inputs.ndim != 3 or inputs.shape[0] != 3 or inputs.shape[2] != 3:
             raise ValueError(f"inputs: expected (3, B, 3), got {tuple(inputs.shape)}")
         suf = self.be.suffix(inputs)
@@ -353,7 +367,7 @@ class Ops:
         pin = self.be.ptr(inputs)
         self.lib.call("solve", suf, B, pin, pin + step, (pin + 2 * step) if params.has_goal else 0, self.be.ptr(x0),
                       base + o_x, base + o_info, base + o_acc, base + o_att, base + o_rates, base + o_thr,
-                      self.be.stream(), params=params)
+                      self.be.stream() if stream is None else stream, params=params)
         return out
 
     @staticmethod
@@ -370,11 +384,15 @@ class Ops:
         return self._packed_offsets(B, N, 4 if suffix == "f32" else 8)[-1]
 
     def unpack_solution(self, host_bytes: np.ndarray, B: int, N: int, suffix: str):
-        """Host-side views into a packed result (no copies except the float64 cast for f32)."""
+        """Decode a packed result into float64 arrays that do not alias `host_bytes` (which the caller reuses):
+        f64 = ONE copy of the buffer and views into it, f32 = one widening cast per field."""
         esz, dt = (4, np.float32) if suffix == "f32" else (8, np.float64)
         o_x, o_acc, o_att, o_rates, o_thr, o_info, end = self._packed_offsets(B, N, esz)
-        raw = host_bytes
-        f = lambda lo, cnt, shape: np.frombuffer(raw, dtype=dt, count=cnt, offset=lo).reshape(shape).astype(np.float64)
+        raw = host_bytes[:end].copy()
+        if esz == 8:
+            f = lambda lo, cnt, shape: np.frombuffer(raw, dtype=dt, count=cnt, offset=lo).reshape(shape)
+        else:
+            f = lambda lo, cnt, shape: np.frombuffer(raw, dtype=dt, count=cnt, offset=lo).reshape(shape).astype(np.float64)
         return dict(x=f(o_x, B * 9 * N, (B, 9 * N)), accelerations=f(o_acc, B * 3 * N, (B, N, 3)),
                     attitudes=f(o_att, B * 3 * N, (B, N, 3)), body_rates=f(o_rates, B * 3 * N, (B, N, 3)),
                     thrusts=f(o_thr, B * N, (B, N)), info=np.frombuffer(raw, dtype=INFO_DTYPE, count=B, offset=o_info))

@@ -99,6 +99,9 @@ class SE3MPCPlanner(BasePlanner):
         self._device = device
         self._ops = None
         self._io = {}
+        self._params_sig = None
+        self._params_cached = None
+        self.host_mapped_max_problems = 16      # at most this many problems: zero-copy through pinned host memory
         self.logger = _log
 
     # ------------------------------------------------------------------ device plumbing
@@ -110,17 +113,22 @@ class SE3MPCPlanner(BasePlanner):
 
     def _params(self, **overrides) -> Params:
         c = self.se3_config
-        p = Params.reference_defaults(
-            horizon=c.prediction_horizon, dt=c.dt, mass=self.mass, gravity=self.gravity,
-            position_weight=c.position_weight, velocity_weight=c.velocity_weight,
-            acceleration_weight=c.acceleration_weight, thrust_weight=c.thrust_weight,
-            max_velocity=c.max_velocity, max_acceleration=c.max_acceleration, max_thrust=c.max_thrust,
-            min_thrust=c.min_thrust, max_tilt_angle=c.max_tilt_angle, safety_margin=c.safety_margin,
-            max_iterations=c.max_iterations, pgtol=c.convergence_tolerance, ftol=10 * c.convergence_tolerance,
-            has_goal=int(self.goal_position is not None))
-        for k, v in overrides.items():
-            setattr(p, k, v)
-        return p
+        has_goal = int(self.goal_position is not None)
+        # the struct is rebuilt only when a value it carries changed (the config object is mutable)
+        sig = (c.prediction_horizon, c.dt, self.mass, self.gravity, c.position_weight, c.velocity_weight,
+               c.acceleration_weight, c.thrust_weight, c.max_velocity, c.max_acceleration, c.max_thrust, c.min_thrust,
+               c.max_tilt_angle, c.safety_margin, c.max_iterations, c.convergence_tolerance, has_goal)
+        if self._params_sig != sig:
+            self._params_cached = Params.reference_defaults(
+                horizon=c.prediction_horizon, dt=c.dt, mass=self.mass, gravity=self.gravity,
+                position_weight=c.position_weight, velocity_weight=c.velocity_weight,
+                acceleration_weight=c.acceleration_weight, thrust_weight=c.thrust_weight,
+                max_velocity=c.max_velocity, max_acceleration=c.max_acceleration, max_thrust=c.max_thrust,
+                min_thrust=c.min_thrust, max_tilt_angle=c.max_tilt_angle, safety_margin=c.safety_margin,
+                max_iterations=c.max_iterations, pgtol=c.convergence_tolerance, ftol=10 * c.convergence_tolerance,
+                has_goal=has_goal)
+            self._params_sig = sig
+        return self._params_cached.copy(**overrides) if overrides else self._params_cached
 
     # ------------------------------------------------------------------ planner.py:175-228
     def set_goal(self, goal_position) -> None:
@@ -137,8 +145,12 @@ class SE3MPCPlanner(BasePlanner):
 
     def sense(self, current_state: DroneState, goal_position):
         goal_position = ensure_units(goal_position, "m", "SE3MPCPlanner.sense goal_position")
-        if self.goal_position is None or np.linalg.norm(to_float(self.goal_position - goal_position)) > 0.5:
-            self.set_goal(goal_position)                                        # planner.py:197-201
+        if self.goal_position is None:
+            self.set_goal(goal_position)
+        else:
+            d = np.asarray(to_float(self.goal_position), float) - goal_position
+            if float(d @ d) > 0.25:                                             # planner.py:197-201 (norm > 0.5 m)
+                self.set_goal(goal_position)
         return current_state, self.goal_position, list(self.obstacles)
 
     def plan(self, current_state: DroneState) -> Dict[str, np.ndarray]:
@@ -181,9 +193,10 @@ class SE3MPCPlanner(BasePlanner):
 
     def _solve_batch(self, p0, v0, goal, x0, precision, want_trajectory=True) -> Dict[str, np.ndarray]:
         """B problems in one launch; host float64 arrays in, host float64 arrays out.  Steady state: the
-        stacked (p0, v0, goal) is written into a pinned host buffer, ONE async H2D copy, one launch, ONE
-        async D2H copy of the packed result into a pinned buffer, one stream synchronise; the returned
-        arrays are fresh copies decoded from that buffer."""
+        stacked (p0, v0, goal) is written into a pinned host buffer, then either (a handful of problems)
+        the kernel works on the pinned buffers in place, or ONE async H2D copy, one launch and ONE async D2H
+        copy of the packed result; one stream synchronise; the returned arrays are fresh copies decoded from
+        the pinned result buffer."""
         import torch
         ops = self._get_ops()
         dev = ops.be.device
@@ -191,29 +204,43 @@ class SE3MPCPlanner(BasePlanner):
         dt = torch.float32 if suf == "f32" else torch.float64
         B, N = p0.shape[0], self.se3_config.prediction_horizon
         prm = self._params(has_goal=int(goal is not None))
-        key = (B, N, suf)
+        mapped = B <= self.host_mapped_max_problems
+        key = (B, N, suf, mapped)
         io = self._io
         if io.get("key") != key:
             pin = dev.type == "cuda"
             nbytes = ops.packed_size(B, N, suf)
             io = self._io = dict(key=key,
                                  h_in=torch.empty((3, B, 3), dtype=dt, pin_memory=pin),
-                                 d_in=torch.empty((3, B, 3), dtype=dt, device=dev),
-                                 d_out=ops.be.empty((nbytes,), "u8"),
                                  h_out=torch.empty((nbytes,), dtype=torch.uint8, pin_memory=pin))
+            if mapped:
+                io["h_x0"] = torch.empty((B, 9 * N), dtype=dt, pin_memory=pin)
+                io["h_x0_np"] = io["h_x0"].numpy()
+            else:
+                io["d_in"] = torch.empty((3, B, 3), dtype=dt, device=dev)
+                io["d_out"] = ops.be.empty((nbytes,), "u8")
             io["h_in_np"] = io["h_in"].numpy()
             io["h_out_np"] = io["h_out"].numpy()
+        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+        stream_handle = None if cur is None else cur.cuda_stream
         hin = io["h_in_np"]
         hin[0] = p0; hin[1] = v0
         hin[2] = goal if goal is not None else 0.0
-        io["d_in"].copy_(io["h_in"], non_blocking=True)
-        dx0 = None if x0 is None else torch.from_numpy(np.ascontiguousarray(x0)).to(device=dev, dtype=dt)
-        ops.solve_packed(prm, io["d_in"], x0=dx0, out=io["d_out"])
-        io["h_out"].copy_(io["d_out"], non_blocking=True)
-        if dev.type == "cuda":
-            torch.cuda.current_stream(dev).synchronize()
+        if mapped:
+            # a handful of problems: the kernel reads the pinned inputs and writes the pinned result in place
+            hx0 = None
+            if x0 is not None:
+                io["h_x0_np"][...] = x0
+                hx0 = io["h_x0"]
+            ops.solve_packed(prm, io["h_in"], x0=hx0, out=io["h_out"], host_mapped=True, stream=stream_handle)
+        else:
+            io["d_in"].copy_(io["h_in"], non_blocking=True)
+            dx0 = None if x0 is None else torch.from_numpy(np.ascontiguousarray(x0)).to(device=dev, dtype=dt)
+            ops.solve_packed(prm, io["d_in"], x0=dx0, out=io["d_out"])
+            io["h_out"].copy_(io["d_out"], non_blocking=True)
+        if cur is not None:
+            cur.synchronize()
         res = ops.unpack_solution(io["h_out_np"], B, N, suf)
-        res["info"] = np.array(res["info"])      # the arrays are astype() copies; info is a view into the pinned buffer
         x = res["x"]
         res.update(positions=x[:, :3 * N].reshape(B, N, 3), velocities=x[:, 3 * N:6 * N].reshape(B, N, 3),
                    thrust_vectors=x[:, 6 * N:].reshape(B, N, 3))

@@ -58,6 +58,9 @@ class TorchCpuBackend:
     def ptr(self, a):
         return 0 if a is None else a.data_ptr()
 
+    def is_host_mapped(self, a):
+        return self.torch.is_tensor(a) and a.is_contiguous()      # the emulated device IS host memory
+
     def stream(self):
         return 0
 
