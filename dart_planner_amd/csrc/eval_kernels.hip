@@ -536,27 +536,98 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
   }
 }
 
+// Sphere residuals of one wavefront's share of the steps (k = w, w+W, ...) against the LDS-resident table.
+// The spheres are walked in register chunks of 8: one chunk is fetched once (broadcast LDS reads) and then
+// swept over all of the wavefront's steps, so the inner loop costs 3 LDS reads per 8 evaluations instead of a
+// 16-byte read per evaluation, and nothing in it waits on LDS.  f32 evaluates two spheres per instruction
+// (v_pk_add/mul/fma_f32).  The table is padded to a multiple of 8 with (0, 0, 0, -inf): residual +inf.
+constexpr int kSphereChunk = 8;
+
+template <typename R>
+__device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int w,
+                                               int W, int lane, R& mn_out, R& vs_out) {
+  R mn = INFINITY;
+  if constexpr (sizeof(R) == 4) {
+    typedef float f2 __attribute__((vector_size(8)));
+    f2 vs2 = {0.0f, 0.0f};
+    for (int j0 = 0; j0 < Kpad; j0 += kSphereChunk) {
+      f2 cx[kSphereChunk / 2], cy[kSphereChunk / 2], cz[kSphereChunk / 2], r2[kSphereChunk / 2];
+#pragma unroll
+      for (int jj = 0; jj < kSphereChunk / 2; ++jj) {
+        const R* s0 = sph + 4 * (j0 + 2 * jj);
+        cx[jj] = f2{s0[0], s0[4]}; cy[jj] = f2{s0[1], s0[5]}; cz[jj] = f2{s0[2], s0[6]}; r2[jj] = f2{s0[3], s0[7]};
+      }
+#pragma unroll 2
+      for (int k = w; k < Nn; k += W) {
+        const float px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
+                    pz = tile[((size_t)2 * Nn + k) * kWave + lane];
+        const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
+#pragma unroll
+        for (int jj = 0; jj < kSphereChunk / 2; ++jj) {
+          const f2 dx = px2 - cx[jj], dy = py2 - cy[jj], dz = pz2 - cz[jj];
+          const f2 cj = (dx * dx + dy * dy + dz * dz) - r2[jj];
+          mn = fminf(mn, fminf(cj[0], cj[1]));
+          vs2 += f2{fmaxf(0.0f, -cj[0]), fmaxf(0.0f, -cj[1])};
+        }
+      }
+    }
+    vs_out = vs2[0] + vs2[1];
+  } else {
+    R vs = (R)0;
+    for (int j0 = 0; j0 < Kpad; j0 += kSphereChunk) {
+      R cx[kSphereChunk], cy[kSphereChunk], cz[kSphereChunk], r2[kSphereChunk];
+#pragma unroll
+      for (int jj = 0; jj < kSphereChunk; ++jj) {
+        const R* s0 = sph + 4 * (j0 + jj);
+        cx[jj] = s0[0]; cy[jj] = s0[1]; cz[jj] = s0[2]; r2[jj] = s0[3];
+      }
+      for (int k = w; k < Nn; k += W) {
+        const R px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
+                pz = tile[((size_t)2 * Nn + k) * kWave + lane];
+#pragma unroll
+        for (int jj = 0; jj < kSphereChunk; ++jj) {
+          const R dx = px - cx[jj], dy = py - cy[jj], dz = pz - cz[jj];
+          const R cj = (dx * dx + dy * dy + dz * dz) - r2[jj];
+          mn = fmin(mn, cj);
+          vs += fmax((R)0, -cj);
+        }
+      }
+    }
+    vs_out = vs;
+  }
+  mn_out = mn;
+}
+
 // Rollout fused with the sphere-obstacle residuals of planner.py:499-514 on the ROLLED-OUT positions
 // (BASELINE.json config 3: horizon 50, K = 16 spheres from the mapper).  The forward sweep of each axis
 // wavefront stages its positions as a per-step tile in LDS ([axis][k][lane], bank = lane: conflict free);
-// after the barrier the three wavefronts split the steps (k = w, w+3, ...) and evaluate
+// after the barrier the W wavefronts of the workgroup split the steps (k = w, w+W, ...) and evaluate
 // |P_k - c_j|^2 - (r_j + margin)^2 against the LDS-resident sphere table, keeping the minimum residual and
 // the summed violation per trajectory.  Neither the states nor the N*K residuals ever touch HBM:
 // 4*(6N+12) B per rollout instead of 4*(6N+10) + 4*(3N) written + 4*(3N) re-read for the unfused pair.
-template <typename R, int N, bool REG, bool GRAD>
-__global__ void __launch_bounds__(192)
+// W = 3: the axis wavefronts do everything (saturating batches).  W = 8: five more wavefronts wait at the
+// barrier and then take their share of the N*K evaluations -- for batches that leave SIMDs idle
+// (8192 rollouts = 128 workgroups) the evaluation phase is the critical path and this shortens it.
+template <typename R, int N, bool REG, bool GRAD, int W>
+__global__ void __launch_bounds__(64 * W)
 rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
                          const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
                          R* __restrict__ gradT, const R* __restrict__ spheres, int K, R* __restrict__ cmin,
                          R* __restrict__ viol, unsigned long long* __restrict__ key, uint32_t index_base) {
   HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  const int Kpad = (K + kSphereChunk - 1) / kSphereChunk * kSphereChunk;
   R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]
-  R* sph = tile + (size_t)3 * q.N * kWave;                   // [K][4] = (cx, cy, cz, (r + margin)^2)
-  R* part = sph + (size_t)4 * K;                             // [3][3][64]: cost, min residual, violation per axis wave
-  for (int i = threadIdx.x; i < K; i += blockDim.x) {
-    sph[4 * i + 0] = spheres[4 * i + 0]; sph[4 * i + 1] = spheres[4 * i + 1]; sph[4 * i + 2] = spheres[4 * i + 2];
-    const R sm = spheres[4 * i + 3] + q.margin;
-    sph[4 * i + 3] = sm * sm;
+  R* sph = tile + (size_t)3 * q.N * kWave;                   // [Kpad][4] = (cx, cy, cz, (r + margin)^2)
+  R* part = sph + (size_t)4 * Kpad;                          // [3 + 2W][64]: axis costs, then min residual / violation per wave
+  // the sphere table is fetched into registers now and written to LDS after the rollout: its HBM latency hides
+  // behind the rollout's own loads instead of preceding them (K <= 256, >= 192 threads: at most two rows each)
+  constexpr int kRowsPerThread = (SE3MPC_MAX_SPHERES + 64 * W - 1) / (64 * W);
+  R srow[kRowsPerThread][4];
+#pragma unroll
+  for (int t = 0; t < kRowsPerThread; ++t) {
+    const int i = threadIdx.x + t * 64 * W;
+    srow[t][0] = (R)0; srow[t][1] = (R)0; srow[t][2] = (R)0; srow[t][3] = (R)0;
+    if (i < K) { srow[t][0] = spheres[4 * i + 0]; srow[t][1] = spheres[4 * i + 1]; srow[t][2] = spheres[4 * i + 2]; srow[t][3] = spheres[4 * i + 3]; }
   }
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
@@ -567,32 +638,39 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
   const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int a = wave_uniform((int)(threadIdx.x / kWave));
   const int Nn = q.N;
-  R* my_tile = tile + (size_t)a * Nn * kWave + lane;
-  R c;
-  if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, false, 2, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
-  else c = rollout_axis_rev<R, GRAD, false, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
-  part[(0 * 3 + a) * kWave + lane] = c;
-  __syncthreads();
-  R mn = INFINITY, vs = (R)0;
-  for (int k = a; k < Nn; k += 3) {
-    const R px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
-            pz = tile[((size_t)2 * Nn + k) * kWave + lane];
-    for (int j = 0; j < K; ++j) {
-      const R dx = px - sph[4 * j + 0], dy = py - sph[4 * j + 1], dz = pz - sph[4 * j + 2];
-      const R cj = (dx * dx + dy * dy + dz * dz) - sph[4 * j + 3];
-      mn = fmin(mn, cj);
-      vs += fmax((R)0, -cj);
+  if (a < 3) {
+    R* my_tile = tile + (size_t)a * Nn * kWave + lane;
+    R c;
+    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, false, 2, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
+    else c = rollout_axis_rev<R, GRAD, false, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
+    part[a * kWave + lane] = c;
+  }
+#pragma unroll
+  for (int t = 0; t < kRowsPerThread; ++t) {
+    const int i = threadIdx.x + t * 64 * W;
+    if (i < Kpad) {
+      const R sm = srow[t][3] + q.margin;
+      sph[4 * i + 0] = srow[t][0]; sph[4 * i + 1] = srow[t][1]; sph[4 * i + 2] = srow[t][2];
+      sph[4 * i + 3] = i < K ? sm * sm : (R)-INFINITY;
     }
   }
-  part[(1 * 3 + a) * kWave + lane] = mn;
-  part[(2 * 3 + a) * kWave + lane] = vs;
   __syncthreads();
-  const R total = part[0 * kWave + lane] + part[1 * kWave + lane] + part[2 * kWave + lane];
-  if (live && a == 0) {
-    if (cmin != nullptr) cmin[b] = fmin(part[3 * kWave + lane], fmin(part[4 * kWave + lane], part[5 * kWave + lane]));
-    if (viol != nullptr) viol[b] = part[6 * kWave + lane] + part[7 * kWave + lane] + part[8 * kWave + lane];
+  R mn, vs;
+  obstacle_sweep<R>(tile, sph, Nn, Kpad, a, W, lane, mn, vs);
+  part[(3 + a) * kWave + lane] = mn;
+  part[(3 + W + a) * kWave + lane] = vs;
+  __syncthreads();
+  if (a == 0) {
+    const R total = part[0 * kWave + lane] + part[1 * kWave + lane] + part[2 * kWave + lane];
+    if (live) {
+      R m = part[3 * kWave + lane], v = part[(3 + W) * kWave + lane];
+#pragma unroll
+      for (int w = 1; w < W; ++w) { m = fmin(m, part[(3 + w) * kWave + lane]); v += part[(3 + W + w) * kWave + lane]; }
+      if (cmin != nullptr) cmin[b] = m;
+      if (viol != nullptr) viol[b] = v;
+    }
+    rollout_epilogue<R>(live, b, total, cost, key != nullptr ? key + blk : nullptr, index_base);
   }
-  rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
 }
 
 template <typename R, bool GRAD, bool STATES>
@@ -971,7 +1049,7 @@ int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   if ((P == nullptr) != (V == nullptr)) return SE3MPC_ERR_NULL;   // states come as a pair
   if ((uint64_t)3 * p->horizon * (uint64_t)ld * sizeof(R) >= (1ull << 32)) return SE3MPC_ERR_SHAPE;   // 32-bit buffer offsets
   hipStream_t s = (hipStream_t)stream;
-  const int var = g_rollout_variant;
+  const int var = g_rollout_variant & 127;
   const bool grad = gradT != nullptr, states = P != nullptr;
   if (grad && states) return rollout_launch<R, true, true>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, nbatch, s);
   if (grad) return rollout_launch<R, true, false>(p, var, B, ld, p0, v0, goal, T, cost, gradT, P, V, key, index_base, nbatch, s);
@@ -991,22 +1069,31 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
   const DevParams<R> q = make_dev_params<R>(*p);
   const int N = p->horizon, nblk = grid_for(B, kWave);
-  const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * K + (size_t)9 * kWave) * sizeof(R);
+  const int Kpad = (K + kSphereChunk - 1) / kSphereChunk * kSphereChunk;
+  // 8 wavefronts per workgroup while that still leaves SIMDs idle (the chip holds 1024 single-wave slots
+  // before any wavefront has to share a SIMD), 3 otherwise; se3mpc_set_rollout_variant(+128 / +256) forces 3 / 8
+  const int wsel = (g_rollout_variant >> 7) & 3;
+  const bool wide = wsel == 2 || (wsel == 0 && (long long)nblk * 8 <= 1024);
+  const int W = wide ? 8 : 3;
+  const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
   hipStream_t s = (hipStream_t)stream;
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
-#define SE3MPC_OBST(NN, REG, GRAD)                                                                                    \
-  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD>), dim3(nblk), dim3(192), lds, s, q, B, ld, p0, v0, goal, \
-                     T, cost, gradT, spheres, K, cmin, viol, key, index_base)
-#define SE3MPC_OBST_N(GRAD)                                                     \
-  if (!has_reg) SE3MPC_OBST(0, false, GRAD);                                    \
-  else if (N == 6) SE3MPC_OBST(6, true, GRAD);                                  \
-  else if (N == 20) SE3MPC_OBST(20, true, GRAD);                                \
-  else if constexpr (sizeof(R) == 4) {                                          \
-    if (N == 30) SE3MPC_OBST(30, true, GRAD); else SE3MPC_OBST(50, true, GRAD); \
+#define SE3MPC_OBST_W(NN, REG, GRAD, WW)                                                                                 \
+  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW>), dim3(nblk), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
+                     goal, T, cost, gradT, spheres, K, cmin, viol, key, index_base)
+#define SE3MPC_OBST(NN, REG, GRAD) \
+  if (wide) SE3MPC_OBST_W(NN, REG, GRAD, 8); else SE3MPC_OBST_W(NN, REG, GRAD, 3)
+#define SE3MPC_OBST_N(GRAD)                                                         \
+  if (!has_reg) { SE3MPC_OBST(0, false, GRAD); }                                    \
+  else if (N == 6) { SE3MPC_OBST(6, true, GRAD); }                                  \
+  else if (N == 20) { SE3MPC_OBST(20, true, GRAD); }                                \
+  else if constexpr (sizeof(R) == 4) {                                              \
+    if (N == 30) { SE3MPC_OBST(30, true, GRAD); } else { SE3MPC_OBST(50, true, GRAD); } \
   }
   if (gradT != nullptr) { SE3MPC_OBST_N(true) } else { SE3MPC_OBST_N(false) }
 #undef SE3MPC_OBST_N
 #undef SE3MPC_OBST
+#undef SE3MPC_OBST_W
   return launch_status("se3mpc_rollout_obstacles");
 }
 
@@ -1131,7 +1218,7 @@ extern "C" int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int 
 }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
+  if (variant < 0 || variant >= 384 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
   se3mpc::g_rollout_variant = variant;
   return SE3MPC_OK;
 }

@@ -209,8 +209,9 @@ int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uin
  * with one wavefront looping over the three axes, 6 = 32-step register bucket with guarded steps (f32, horizons 17..32;
  * else 3).  variant + 8 * (flags + 1) forces the memory-policy
  * flags of the benchmarked instantiation (horizon 30, f32, gradient): bit 0 nt loads, bit 1 nt stores,
- * bit 2 XCD-contiguous block order; the default is all three (7).  All compute the same quantities
- * (DESIGN.md section 5). */
+ * bit 2 XCD-contiguous block order; the default is all three (7).  + 128 / + 256 forces the workgroup of
+ * se3mpc_rollout_obstacles_* to 3 / 8 wavefronts (default: 8 while 8 x workgroups <= 1024, else 3).
+ * All compute the same quantities. */
 int se3mpc_set_rollout_variant(int variant);
 
 /* Replaces is_plan_valid (planner.py:717-737): valid[b] = 1 iff all positions finite,

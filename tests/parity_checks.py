@@ -158,12 +158,21 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
         ki = int(h.to_host(keysb)[i]) & 0xFFFFFFFFFFFFFFFF
         assert h.ops.lib.key_index(ki) == 11 + int(np.argmin(h.to_host(ci)))
     # rollout fused with the obstacle residuals of the rolled-out positions (config 3) == rollout, then a9 on its states
-    co, go, cmn, vio = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B), h.prob(sph))
-    assert np.max(np.abs(h.to_host(co).astype(float) - c_ref) / np.abs(c_ref)) <= t["cost_rel"], "fused rollout cost"
-    vec_close(h.unlane(go, (B, N, 3)), g_ref, t["vec_rel"], "fused rollout gradient")
-    Cr = orc.obstacle_residual(orc.pack(P_ref, V_ref, T), sph[:, :3], sph[:, 3], cfg)
-    vec_close(h.to_host(cmn), Cr.min(1), t["vec_rel"] * 4, "fused obstacle min")
-    vec_close(h.to_host(vio), np.maximum(0, -Cr).sum(1), t["vec_rel"] * 8, "fused obstacle violation")
+    # (both workgroup shapes: +128 = the 3 axis wavefronts do the evaluations, +256 = 8 wavefronts share them;
+    #  sphere counts that are not a multiple of the register chunk of 8)
+    Cr_all = orc.obstacle_residual(orc.pack(P_ref, V_ref, T), sph[:, :3], sph[:, 3], cfg).reshape(B, N, -1)
+    try:
+        for wsel, Ks in ((128, len(sph)), (256, len(sph)), (128, 3), (256, 9), (0, len(sph))):
+            h.ops.lib.set_rollout_variant(wsel)
+            co, go, cmn, vio = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
+                                                       h.prob(sph[:Ks]))
+            assert np.max(np.abs(h.to_host(co).astype(float) - c_ref) / np.abs(c_ref)) <= t["cost_rel"], "fused rollout cost"
+            vec_close(h.unlane(go, (B, N, 3)), g_ref, t["vec_rel"], "fused rollout gradient")
+            Cr = Cr_all[:, :, :Ks].reshape(B, -1)
+            vec_close(h.to_host(cmn), Cr.min(1), t["vec_rel"] * 4, f"fused obstacle min (variant {wsel}, K={Ks})")
+            vec_close(h.to_host(vio), np.maximum(0, -Cr).sum(1), t["vec_rel"] * 8, f"fused obstacle violation (variant {wsel}, K={Ks})")
+    finally:
+        h.ops.lib.set_rollout_variant(0)
     co2, g_none, cmn2, _ = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
                                                    h.prob(np.zeros((0, 4))), want_grad=False)
     assert g_none is None and np.all(np.isinf(h.to_host(cmn2))) and np.allclose(h.to_host(co2), h.to_host(co), rtol=t["cost_rel"])
