@@ -91,9 +91,17 @@ class SolveInfo(C.Structure):
                 ("task", C.c_int32)]
 
 
+class VoxelMapDesc(C.Structure):
+    """struct se3mpc_voxel_map: the caller-owned hash table of the device voxel map (device addresses)."""
+    _fields_ = [("keys", C.c_void_p), ("prob", C.c_void_p), ("count", C.c_void_p), ("capacity", C.c_int32),
+                ("reserved", C.c_int32), ("resolution", C.c_double), ("prior", C.c_double)]
+
+
 _P = C.c_void_p
 _I = C.c_int
+_D = C.c_double
 _PP = C.POINTER(Params)
+_VP = C.POINTER(VoxelMapDesc)
 
 # name -> argtypes after the leading (const se3mpc_params*) when `params` is True
 _TYPED_API = {
@@ -111,6 +119,19 @@ _TYPED_API = {
     "spheres_from_grid": (False, [_P, _P, _I, C.c_double, _I, C.c_double, _P, _I, _P, _P]),
     "transpose": (False, [_I, _I, _P, _I, _P, _I, _P]),
     "solve": (True, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+}
+# voxel map: se3mpc_voxel_<base>_<suffix>(const se3mpc_voxel_map*, ...)
+_VOXEL_TYPED_API = {
+    "query": [_P, _I, _P, _P],
+    "trajectory_safe": [_P, _I, _I, C.c_longlong, _D, _D, _P, _P, _P],
+    "local_spheres": [C.POINTER(C.c_double * 3), _D, _D, _I, _D, _P, _I, _P, _P, _P],
+}
+_VOXEL_PLAIN_API = {
+    "se3mpc_voxel_clear": (C.c_int, [_VP, _P]),
+    "se3mpc_voxel_insert": (C.c_int, [_VP, _P, _P, _D, _P, _I, _P, _P]),
+    "se3mpc_voxel_update_rays": (C.c_int, [_VP, _P, _P, _P, _P, _I, _D, _D, _P, _P, _I, _P, _P]),
+    "se3mpc_voxel_export": (C.c_int, [_VP, _P, _P, _P, _P, _P]),
+    "se3mpc_voxel_local_workspace": (C.c_int, [_I]),
 }
 _PLAIN_API = {
     "se3mpc_abi_version": (C.c_int, []),
@@ -130,6 +151,9 @@ def exported_symbols() -> list:
     names = list(_PLAIN_API)
     for base in _TYPED_API:
         names += [f"se3mpc_{base}_f32", f"se3mpc_{base}_f64"]
+    names += list(_VOXEL_PLAIN_API)
+    for base in _VOXEL_TYPED_API:
+        names += [f"se3mpc_voxel_{base}_f32", f"se3mpc_voxel_{base}_f64"]
     return names
 
 
@@ -159,6 +183,14 @@ class Library:
                 fn = getattr(self._dll, f"se3mpc_{base}_{suf}")
                 fn.restype = C.c_int
                 fn.argtypes = ([_PP] if has_params else []) + args
+        for name, (res, args) in _VOXEL_PLAIN_API.items():
+            fn = getattr(self._dll, name)
+            fn.restype, fn.argtypes = res, args
+        for base, args in _VOXEL_TYPED_API.items():
+            for suf in ("f32", "f64"):
+                fn = getattr(self._dll, f"se3mpc_voxel_{base}_{suf}")
+                fn.restype = C.c_int
+                fn.argtypes = [_VP] + args
         if self._dll.se3mpc_abi_version() != 1:
             raise Se3mpcLibraryError(f"{self.path}: ABI version {self._dll.se3mpc_abi_version()} != 1")
 
@@ -211,6 +243,17 @@ class Library:
         if _TYPED_API[base][0]:
             return fn(C.byref(params) if params is not None else None, *args)
         return fn(*args)
+
+    # -- voxel map ----------------------------------------------------------------------------
+    def voxel(self, name: str, desc: VoxelMapDesc, *args) -> None:
+        """Call se3mpc_voxel_<name>(&desc, *args) (name = 'clear', 'insert', 'export', 'query_f32', ...)."""
+        self._check(f"se3mpc_voxel_{name}", getattr(self._dll, f"se3mpc_voxel_{name}")(C.byref(desc), *args))
+
+    def voxel_status(self, name: str, desc: Optional[VoxelMapDesc], *args) -> int:
+        return getattr(self._dll, f"se3mpc_voxel_{name}")(C.byref(desc) if desc is not None else None, *args)
+
+    def voxel_local_workspace(self, cells_per_axis: int) -> int:
+        return self._dll.se3mpc_voxel_local_workspace(cells_per_axis)
 
     def _check(self, name: str, rc: int) -> None:
         if rc != 0:

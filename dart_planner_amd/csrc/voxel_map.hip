@@ -1,0 +1,561 @@
+// voxel_map.hip -- device-resident voxel map: the obstacle source of the SE(3) MPC path.
+//
+// Counterpart of ExplicitGeometricMapper (reference src/dart_planner/perception/explicit_geometric_mapper.py,
+// "mapper.py" below).  The reference keeps a Python dict {(ix, iy, iz): VoxelData} and answers every query with a dict
+// lookup (one million of them for the default 20 m / 0.2 m local grid of get_local_occupancy_grid, each planning
+// cycle of cloud/main_improved_threelayer.py:381-398).  Here the dict is an open-addressing hash table in HBM
+// (64-bit packed key, linear probing, multiplicative hash); it is tens of kilobytes to a few megabytes, so it lives
+// in L2 / Infinity Cache and every kernel below is bound by hash probes and integer/f64 index arithmetic, not by HBM
+// streams.  Voxel indices and probabilities follow the reference's float64 arithmetic operation by operation
+// (floor(p / resolution), numpy.linspace's i * step + start with the last point pinned, no FMA contraction),
+// so results are bit-identical to the reference's (tests/golden/mapper_map.npz).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "se3mpc_common.hpp"
+#include <se3mpc_wave_ops.hpp>
+
+namespace se3mpc {
+
+struct VoxDev {
+  unsigned long long* keys;
+  double* prob;
+  int32_t* count;
+  uint32_t mask;
+  int shift;          // 64 - log2(capacity)
+  double res, prior;
+};
+
+constexpr long long kVoxBias = 1ll << 20;
+constexpr int kVoxOut = INT32_MIN;             // axis index outside the packable range
+constexpr unsigned long long kVoxEmpty = SE3MPC_VOXEL_EMPTY;
+
+static int make_vox_dev(const se3mpc_voxel_map* m, VoxDev& d) {
+  if (m == nullptr || m->keys == nullptr || m->prob == nullptr || m->count == nullptr) return SE3MPC_ERR_NULL;
+  const int cap = m->capacity;
+  if (cap < 64 || (cap & (cap - 1)) != 0) return SE3MPC_ERR_SHAPE;
+  if (!(m->resolution > 0.0) || !std::isfinite(m->resolution) || !std::isfinite(m->prior)) return SE3MPC_ERR_PARAM;
+  int lg = 0;
+  while ((1 << lg) < cap) ++lg;
+  d.keys = reinterpret_cast<unsigned long long*>(m->keys);
+  d.prob = m->prob;
+  d.count = m->count;
+  d.mask = (uint32_t)cap - 1u;
+  d.shift = 64 - lg;
+  d.res = m->resolution;
+  d.prior = m->prior;
+  return SE3MPC_OK;
+}
+
+// world_to_voxel, one axis (mapper.py:93-96): floor(p / resolution) in float64
+__device__ __forceinline__ int vox_axis(double p, double res) {
+  const double v = floor(p / res);
+  return (fabs(v) < (double)kVoxBias) ? (int)v : kVoxOut;      // NaN fails the comparison too
+}
+
+__device__ __forceinline__ bool vox_pack(int ix, int iy, int iz, unsigned long long& key) {
+  if (ix == kVoxOut || iy == kVoxOut || iz == kVoxOut) return false;
+  const long long lim = kVoxBias;
+  if (ix < -lim || ix >= lim || iy < -lim || iy >= lim || iz < -lim || iz >= lim) return false;
+  key = ((unsigned long long)(ix + kVoxBias) << 42) | ((unsigned long long)(iy + kVoxBias) << 21) |
+        (unsigned long long)(iz + kVoxBias);
+  return true;
+}
+
+__device__ __forceinline__ void vox_unpack(unsigned long long key, int& ix, int& iy, int& iz) {
+  ix = (int)((long long)((key >> 42) & 0x1FFFFFull) - kVoxBias);
+  iy = (int)((long long)((key >> 21) & 0x1FFFFFull) - kVoxBias);
+  iz = (int)((long long)(key & 0x1FFFFFull) - kVoxBias);
+}
+
+__device__ __forceinline__ uint32_t vox_hash(const VoxDev& d, unsigned long long key) {
+  return (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> d.shift) & d.mask;
+}
+
+// slot of `key`, or -1 (the table always keeps at least one empty slot per probe run at sane load factors; the
+// loop is bounded by the capacity regardless)
+__device__ __forceinline__ int vox_find(const VoxDev& d, unsigned long long key) {
+  uint32_t h = vox_hash(d, key);
+  for (uint32_t n = 0; n <= d.mask; ++n) {
+    const unsigned long long k = d.keys[h];
+    if (k == key) return (int)h;
+    if (k == kVoxEmpty) return -1;
+    h = (h + 1u) & d.mask;
+  }
+  return -1;
+}
+
+// slot of `key`, claiming a free one if it is new; -1 = table full
+__device__ __forceinline__ int vox_find_or_claim(const VoxDev& d, unsigned long long key) {
+  uint32_t h = vox_hash(d, key);
+  for (uint32_t n = 0; n <= d.mask; ++n) {
+    unsigned long long k = d.keys[h];
+    if (k == kVoxEmpty) k = atomicCAS(&d.keys[h], kVoxEmpty, key);
+    if (k == kVoxEmpty || k == key) return (int)h;
+    h = (h + 1u) & d.mask;
+  }
+  return -1;
+}
+
+// query_occupancy (mapper.py:155-171) by voxel index
+__device__ __forceinline__ double vox_occupancy_idx(const VoxDev& d, int ix, int iy, int iz) {
+  unsigned long long key;
+  if (!vox_pack(ix, iy, iz, key)) return d.prior;
+  const int s = vox_find(d, key);
+  return s < 0 ? d.prior : d.prob[s];
+}
+
+__device__ __forceinline__ double vox_occupancy(const VoxDev& d, double x, double y, double z) {
+  return vox_occupancy_idx(d, vox_axis(x, d.res), vox_axis(y, d.res), vox_axis(z, d.res));
+}
+
+// ------------------------------------------------------------------------------------------ table maintenance
+__global__ void __launch_bounds__(256) voxel_clear_kernel(VoxDev d) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= d.mask; i += gridDim.x * blockDim.x) {
+    d.keys[i] = kVoxEmpty;
+    d.prob[i] = d.prior;
+    d.count[i] = 0;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+voxel_insert_kernel(VoxDev d, const int32_t* __restrict__ ijk, const double* __restrict__ prob, double value,
+                    const int32_t* __restrict__ count_in, int M, int32_t* __restrict__ failed) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  unsigned long long key;
+  int s = -1;
+  if (vox_pack(ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2], key)) s = vox_find_or_claim(d, key);
+  if (s >= 0) {
+    d.prob[s] = prob != nullptr ? prob[i] : value;
+    if (count_in != nullptr) d.count[s] = count_in[i];
+  } else if (failed != nullptr) {
+    atomicAdd(failed, 1);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+voxel_export_kernel(VoxDev d, int32_t* __restrict__ ijk_out, double* __restrict__ prob_out, int32_t* __restrict__ count_out,
+                    int32_t* __restrict__ n_out) {
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i <= d.mask; i += gridDim.x * blockDim.x) {
+    const unsigned long long k = d.keys[i];
+    if (k == kVoxEmpty) continue;
+    const int o = atomicAdd(n_out, 1);
+    int ix, iy, iz;
+    vox_unpack(k, ix, iy, iz);
+    if (ijk_out != nullptr) { ijk_out[3 * o] = ix; ijk_out[3 * o + 1] = iy; ijk_out[3 * o + 2] = iz; }
+    if (prob_out != nullptr) prob_out[o] = d.prob[i];
+    if (count_out != nullptr) count_out[o] = d.count[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------ queries
+// query_occupancy_batch (mapper.py:173-183): one position per lane
+template <typename R>
+__global__ void __launch_bounds__(256)
+voxel_query_kernel(VoxDev d, const R* __restrict__ pos, int M, double* __restrict__ occ) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  occ[i] = vox_occupancy(d, (double)pos[(size_t)3 * i], (double)pos[(size_t)3 * i + 1], (double)pos[(size_t)3 * i + 2]);
+}
+
+// is_trajectory_safe (mapper.py:195-219) with the seven check positions of _get_safety_margin_positions
+// (:339-353): one wavefront per trajectory, lane = step; the first colliding step comes out of one ballot.
+template <typename R>
+__global__ void __launch_bounds__(256)
+voxel_trajectory_safe_kernel(VoxDev d, const R* __restrict__ P, int B, int N, long long stride, double margin, double thr,
+                             int32_t* __restrict__ safe, int32_t* __restrict__ first) {
+  const int lane = lane_id();
+  const int b = blockIdx.x * (blockDim.x / kWave) + (int)(threadIdx.x / kWave);
+  if (b >= B) return;                                          // whole wavefront
+  const R* Pb = P + (size_t)b * (size_t)stride;
+  int found = -1;
+  for (int k0 = 0; k0 < N; k0 += kWave) {
+    const int k = k0 + lane;
+    bool hit = false;
+    if (k < N) {
+      const double c[3] = {(double)Pb[3 * k], (double)Pb[3 * k + 1], (double)Pb[3 * k + 2]};
+      hit = vox_occupancy(d, c[0], c[1], c[2]) > thr;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int sg = -1; sg <= 1; sg += 2) {
+          double q[3] = {c[0], c[1], c[2]};                     // centre + offset, offset = 0 off the axis (mapper.py:347-351)
+          q[a] = c[a] + (double)sg * margin;
+          hit = hit || (vox_occupancy(d, q[0], q[1], q[2]) > thr);
+        }
+      }
+    }
+    const uint64_t m = wave_ballot(hit);
+    if (m != 0ull) { found = k0 + first_lane(m); break; }
+  }
+  if (lane == 0) {
+    if (safe != nullptr) safe[b] = found < 0 ? 1 : 0;
+    if (first != nullptr) first[b] = found;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ local grid -> spheres
+struct GridDev {
+  double start[3], stop[3], step[3];
+  int n;                // cells per axis
+  long long M;          // n^3
+  double thr, radius;
+  int target, cap;
+};
+
+// numpy.linspace(start, stop, n)[i]: i * step + start (two roundings), the last point pinned to stop
+__device__ __forceinline__ double grid_axis_value(const GridDev& g, int a, int i) {
+#pragma clang fp contract(off)
+  if (g.n > 1 && i == g.n - 1) return g.stop[a];
+  const double t = (double)i * g.step[a];
+  return t + g.start[a];
+}
+
+constexpr int kGridRun = 1024;   // consecutive cells owned by one wavefront (16 rows of 64)
+
+// Axis tables in LDS: voxel index of every linspace point, per axis -- 3n divisions per workgroup instead of 3 per cell.
+__device__ __forceinline__ void grid_stage_axes(const VoxDev& d, const GridDev& g, int* ax) {
+  for (int i = threadIdx.x; i < 3 * g.n; i += blockDim.x) {
+    const int a = i / g.n, j = i - a * g.n;
+    ax[i] = vox_axis(grid_axis_value(g, a, j), d.res);
+  }
+  __syncthreads();
+}
+
+// cell m of the reference's flattened grid = (iz, ix, iy), iy fastest (np.array(np.meshgrid(x, y, z)).T.reshape(-1, 3))
+__device__ __forceinline__ bool grid_cell_occupied(const VoxDev& d, const GridDev& g, const int* ax, long long m, int& ix,
+                                                   int& iy, int& iz) {
+  const long long n = g.n;
+  iy = (int)(m % n);
+  ix = (int)((m / n) % n);
+  iz = (int)(m / (n * n));
+  return vox_occupancy_idx(d, ax[ix], ax[g.n + iy], ax[2 * g.n + iz]) > g.thr;
+}
+
+__global__ void __launch_bounds__(256)
+voxel_grid_count_kernel(VoxDev d, GridDev g, int32_t* __restrict__ run_counts) {
+  HIP_DYNAMIC_SHARED(int, ax)
+  grid_stage_axes(d, g, ax);
+  const int lane = lane_id();
+  const long long run = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+  const long long base = run * kGridRun;
+  if (base >= g.M) return;
+  int cnt = 0;
+  for (int r = 0; r < kGridRun / kWave; ++r) {
+    const long long m = base + r * kWave + lane;
+    int ix, iy, iz;
+    const bool o = m < g.M && grid_cell_occupied(d, g, ax, m, ix, iy, iz);
+    cnt += __builtin_popcountll(wave_ballot(o));
+  }
+  if (lane == 0) run_counts[run] = cnt;
+}
+
+template <typename R>
+__global__ void __launch_bounds__(256)
+voxel_grid_select_kernel(VoxDev d, GridDev g, const int32_t* __restrict__ run_counts, int nruns, R* __restrict__ spheres,
+                         int32_t* __restrict__ count) {
+  HIP_DYNAMIC_SHARED(int, ax)
+  grid_stage_axes(d, g, ax);
+  const int lane = lane_id();
+  const long long run = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
+  const long long base = run * kGridRun;
+  if (base >= g.M) return;
+  // rank of this run's first occupied cell and the grand total, from the per-run counts of the first pass
+  int before = 0, total = 0;
+  for (int j = lane; j < nruns; j += kWave) {
+    const int c = run_counts[j];
+    total += c;
+    if (j < run) before += c;
+  }
+  before = wave_sum_i32(before);
+  total = wave_sum_i32(total);
+  const int step = (g.target > 0 && total / g.target > 1) ? total / g.target : 1;   // max(1, n_occupied // target)
+  int rank = before;
+  for (int r = 0; r < kGridRun / kWave; ++r) {
+    const long long m = base + r * kWave + lane;
+    int ix = 0, iy = 0, iz = 0;
+    const bool o = m < g.M && grid_cell_occupied(d, g, ax, m, ix, iy, iz);
+    const uint64_t mask = wave_ballot(o);
+    if (o) {
+      const int rk = rank + __builtin_popcountll(mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+      if (rk % step == 0 && rk / step < g.cap) {
+        R* s4 = spheres + (size_t)4 * (rk / step);
+        s4[0] = (R)grid_axis_value(g, 0, ix); s4[1] = (R)grid_axis_value(g, 1, iy); s4[2] = (R)grid_axis_value(g, 2, iz);
+        s4[3] = (R)g.radius;
+      }
+    }
+    rank += __builtin_popcountll(mask);
+  }
+  if (run == 0 && lane == 0) {
+    const int k = total == 0 ? 0 : (total + step - 1) / step;
+    count[0] = k < g.cap ? k : g.cap;
+    count[1] = total;
+  }
+}
+
+// ------------------------------------------------------------------------------------------ update_map
+// _trace_ray (mapper.py:251-312): the reference's DDA, one ray per lane, float64 operation by operation (no FMA
+// contraction: `end = start + direction * distance` and the boundary arithmetic round twice, as NumPy does).
+// Emits packed voxel keys (EMPTY for a voxel outside the packable range) into ray_keys[ray][0..len).
+__global__ void __launch_bounds__(64)
+voxel_trace_kernel(VoxDev d, const double* __restrict__ origin, const double* __restrict__ direction,
+                   const double* __restrict__ distance, int M, unsigned long long* __restrict__ ray_keys,
+                   int32_t* __restrict__ ray_len, int max_len, int32_t* __restrict__ stats) {
+#pragma clang fp contract(off)
+  const int ray = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ray >= M) return;
+  const double res = d.res, dist = distance[ray];
+  double start[3], dir[3], t_max[3], t_delta[3];
+  long long cur[3], endv[3];
+  int step[3];
+  bool ok = true;
+  for (int a = 0; a < 3; ++a) {
+    start[a] = origin[3 * ray + a];
+    dir[a] = direction[3 * ray + a];
+    const double e = start[a] + dir[a] * dist;                 // mapper.py:268
+    const double c0 = floor(start[a] / res), c1 = floor(e / res);
+    ok = ok && fabs(c0) < 9.0e15 && fabs(c1) < 9.0e15;         // finite and exactly representable
+    cur[a] = ok ? (long long)c0 : 0;
+    endv[a] = ok ? (long long)c1 : 0;
+  }
+  unsigned long long* out = ray_keys + (size_t)ray * (size_t)max_len;
+  int len = 0;
+  bool truncated = false;
+  if (ok) {
+    for (int a = 0; a < 3; ++a) {
+      step[a] = endv[a] > cur[a] ? 1 : (endv[a] < cur[a] ? -1 : 0);
+      if (step[a] != 0) {
+        t_delta[a] = res / fabs(dir[a]);                                         // :285-291
+        const double boundary = (double)(cur[a] + (step[a] > 0 ? 1 : 0)) * res;  // :294-296
+        t_max[a] = fabs((boundary - start[a]) / dir[a]);                         // :298-304
+      } else {
+        t_delta[a] = INFINITY;
+        t_max[a] = INFINITY;
+      }
+    }
+    auto emit = [&]() {
+      if (len < max_len) {
+        unsigned long long key = kVoxEmpty;
+        const long long lim = kVoxBias;
+        if (cur[0] >= -lim && cur[0] < lim && cur[1] >= -lim && cur[1] < lim && cur[2] >= -lim && cur[2] < lim)
+          vox_pack((int)cur[0], (int)cur[1], (int)cur[2], key);
+        out[len++] = key;
+      } else {
+        truncated = true;
+      }
+    };
+    emit();
+    double total = 0.0;
+    while ((cur[0] != endv[0] || cur[1] != endv[1] || cur[2] != endv[2]) && total <= dist && !truncated) {   // :307
+      int axis = 0;                                             // np.argmin: first minimum
+      if (t_max[1] < t_max[axis]) axis = 1;
+      if (t_max[2] < t_max[axis]) axis = 2;
+      cur[axis] += step[axis];
+      total = t_max[axis];
+      t_max[axis] += t_delta[axis];
+      emit();
+    }
+  }
+  ray_len[ray] = len;
+  if (truncated && stats != nullptr) atomicAdd(&stats[2], 1);
+}
+
+// _bayesian_update (mapper.py:314-337)
+__device__ __forceinline__ double vox_bayes(double p, double like) {
+#pragma clang fp contract(off)
+  const double num = like * p;
+  const double den = like * p + (1.0 - like) * (1.0 - p);
+  if (den > 0.0) p = num / den;
+  return fmin(fmax(p, 0.01), 0.99);
+}
+
+// The updates of update_map (mapper.py:114-141) in observation order: the clamped Bayesian update does not commute,
+// so rays are applied one after another; the voxels of ONE ray are distinct and are updated in parallel by the
+// 1024 lanes of a single workgroup.  Between rays: agent-scope fence (so the next ray's loads see this ray's
+// stores through L2) and a workgroup barrier.
+__global__ void __launch_bounds__(1024)
+voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_keys, const int32_t* __restrict__ ray_len,
+                   const int32_t* __restrict__ hit, int M, int max_len, double like_hit, double like_miss,
+                   int32_t* __restrict__ stats) {
+  int updates = 0, lost = 0;
+  for (int ray = 0; ray < M; ++ray) {
+    const int len = ray_len[ray];
+    const bool has_hit = hit[ray] != 0;
+    const unsigned long long* keys = ray_keys + (size_t)ray * (size_t)max_len;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+      const unsigned long long key = keys[i];
+      const int s = key == kVoxEmpty ? -1 : vox_find_or_claim(d, key);
+      if (s < 0) { ++lost; continue; }
+      const bool endpoint = (i == len - 1) && has_hit;                    // :121-123
+      d.prob[s] = vox_bayes(d.prob[s], endpoint ? like_hit : like_miss);
+      d.count[s] += 1;
+      ++updates;
+    }
+    __threadfence();
+    __syncthreads();
+  }
+  if (stats != nullptr) {
+    if (updates) atomicAdd(&stats[0], updates);
+    if (lost) atomicAdd(&stats[1], lost);
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host side
+template <typename R>
+int voxel_query_impl(const se3mpc_voxel_map* m, const R* pos, int M, double* occ, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (M < 0) return SE3MPC_ERR_SHAPE;
+  if (M == 0) return SE3MPC_OK;
+  if (!pos || !occ) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(voxel_query_kernel<R>, dim3(grid_for(M, 256)), dim3(256), 0, (hipStream_t)stream, d, pos, M, occ);
+  return launch_status("se3mpc_voxel_query");
+}
+
+template <typename R>
+int voxel_trajectory_safe_impl(const se3mpc_voxel_map* m, const R* P, int B, int N, long long stride, double margin,
+                               double threshold, int32_t* safe, int32_t* first, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (B < 0 || N < 0 || stride < (long long)3 * N) return SE3MPC_ERR_SHAPE;
+  if (!std::isfinite(margin) || !std::isfinite(threshold)) return SE3MPC_ERR_PARAM;
+  if (B == 0) return SE3MPC_OK;
+  if ((N > 0 && !P) || (!safe && !first)) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(voxel_trajectory_safe_kernel<R>, dim3(grid_for(B, 4)), dim3(256), 0, (hipStream_t)stream, d, P, B, N,
+                     stride, margin, threshold, safe, first);
+  return launch_status("se3mpc_voxel_trajectory_safe");
+}
+
+static int grid_runs(long long M) { return (int)((M + kGridRun - 1) / kGridRun); }
+
+template <typename R>
+int voxel_local_spheres_impl(const se3mpc_voxel_map* m, const double* centre, double size, double threshold, int target,
+                             double radius, R* spheres, int cap, int32_t* count, int32_t* workspace, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (!centre || !count) return SE3MPC_ERR_NULL;
+  if (cap < 0 || target < 1) return SE3MPC_ERR_SHAPE;
+  if (!std::isfinite(size) || !(size >= 0.0) || !std::isfinite(threshold) || !std::isfinite(radius)) return SE3MPC_ERR_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  GridDev g;
+  const double half = size / 2;                              // mapper.py:231-233
+  g.n = (int)(size / m->resolution);                         // num_cells = int(size / resolution)   (:236)
+  if (g.n > SE3MPC_VOXEL_MAX_CELLS) return SE3MPC_ERR_SHAPE;
+  if (g.n < 1) {                                             // linspace(..., 0) is empty: no cells, no spheres
+    if (hipMemsetAsync(count, 0, 2 * sizeof(int32_t), s) != hipSuccess) return launch_status("se3mpc_voxel_local_spheres(memset)");
+    return SE3MPC_OK;
+  }
+  if ((cap > 0 && !spheres) || !workspace) return SE3MPC_ERR_NULL;
+  for (int a = 0; a < 3; ++a) {
+    if (!std::isfinite(centre[a])) return SE3MPC_ERR_PARAM;
+    g.start[a] = centre[a] - half;
+    g.stop[a] = centre[a] + half;
+    const double delta = g.stop[a] - g.start[a];
+    g.step[a] = g.n > 1 ? delta / (double)(g.n - 1) : 0.0;   // numpy.linspace: step = delta / div
+  }
+  g.M = (long long)g.n * g.n * g.n;
+  g.thr = threshold; g.radius = radius; g.target = target; g.cap = cap;
+  const int nruns = grid_runs(g.M);
+  const int nblk = grid_for(nruns, 4);
+  const size_t lds = (size_t)3 * g.n * sizeof(int);
+  hipLaunchKernelGGL(voxel_grid_count_kernel, dim3(nblk), dim3(256), lds, s, d, g, workspace);
+  rc = launch_status("se3mpc_voxel_local_spheres(count)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(voxel_grid_select_kernel<R>, dim3(nblk), dim3(256), lds, s, d, g, workspace, nruns, spheres, count);
+  return launch_status("se3mpc_voxel_local_spheres(select)");
+}
+
+}  // namespace se3mpc
+
+using namespace se3mpc;
+
+extern "C" int se3mpc_voxel_clear(const se3mpc_voxel_map* m, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  int grid = grid_for(m->capacity, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(voxel_clear_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, d);
+  return launch_status("se3mpc_voxel_clear");
+}
+
+extern "C" int se3mpc_voxel_insert(const se3mpc_voxel_map* m, const int32_t* ijk, const double* prob, double value,
+                                   const int32_t* count_in, int M, int32_t* failed, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (M < 0) return SE3MPC_ERR_SHAPE;
+  if (M == 0) return SE3MPC_OK;
+  if (!ijk) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(voxel_insert_kernel, dim3(grid_for(M, 256)), dim3(256), 0, (hipStream_t)stream, d, ijk, prob, value, count_in, M,
+                     failed);
+  return launch_status("se3mpc_voxel_insert");
+}
+
+extern "C" int se3mpc_voxel_export(const se3mpc_voxel_map* m, int32_t* ijk_out, double* prob_out, int32_t* count_out,
+                                   int32_t* n_out, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (!n_out) return SE3MPC_ERR_NULL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(n_out, 0, sizeof(int32_t), s) != hipSuccess) return launch_status("se3mpc_voxel_export(memset)");
+  int grid = grid_for(m->capacity, 256);
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(voxel_export_kernel, dim3(grid), dim3(256), 0, s, d, ijk_out, prob_out, count_out, n_out);
+  return launch_status("se3mpc_voxel_export");
+}
+
+extern "C" int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
+                                        const double* distance, const int32_t* hit, int M, double like_hit, double like_miss,
+                                        uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* stats, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (M < 0 || max_len < 1) return SE3MPC_ERR_SHAPE;
+  if (!(like_hit > 0.0 && like_hit < 1.0 && like_miss > 0.0 && like_miss < 1.0)) return SE3MPC_ERR_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  if (stats != nullptr && hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), s) != hipSuccess)
+    return launch_status("se3mpc_voxel_update_rays(memset)");
+  if (M == 0) return SE3MPC_OK;
+  if (!origin || !direction || !distance || !hit || !ray_keys || !ray_len) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(voxel_trace_kernel, dim3(grid_for(M, 64)), dim3(64), 0, s, d, origin, direction, distance, M,
+                     reinterpret_cast<unsigned long long*>(ray_keys), ray_len, max_len, stats);
+  rc = launch_status("se3mpc_voxel_update_rays(trace)");
+  if (rc) return rc;
+  int threads = 64;                                     // one lane per voxel of the longest possible ray, up to 1024
+  while (threads < max_len && threads < 1024) threads *= 2;
+  hipLaunchKernelGGL(voxel_apply_kernel, dim3(1), dim3(threads), 0, s, d, reinterpret_cast<const unsigned long long*>(ray_keys),
+                     ray_len, hit, M, max_len, like_hit, like_miss, stats);
+  return launch_status("se3mpc_voxel_update_rays(apply)");
+}
+
+extern "C" int se3mpc_voxel_local_workspace(int cells_per_axis) {
+  if (cells_per_axis < 1) return 1;
+  const long long n = cells_per_axis;
+  return grid_runs(n * n * n) + 1;
+}
+
+#define SE3MPC_DEFINE_VOXEL_API(SUF, R)                                                                                    \
+  extern "C" int se3mpc_voxel_query_##SUF(const se3mpc_voxel_map* m, const R* positions, int M, double* occupancy,          \
+                                          void* stream) {                                                                   \
+    return voxel_query_impl<R>(m, positions, M, occupancy, stream);                                                         \
+  }                                                                                                                         \
+  extern "C" int se3mpc_voxel_trajectory_safe_##SUF(const se3mpc_voxel_map* m, const R* P, int B, int N, long long stride,  \
+                                                    double margin, double threshold, int32_t* safe, int32_t* first,         \
+                                                    void* stream) {                                                         \
+    return voxel_trajectory_safe_impl<R>(m, P, B, N, stride, margin, threshold, safe, first, stream);                       \
+  }                                                                                                                         \
+  extern "C" int se3mpc_voxel_local_spheres_##SUF(const se3mpc_voxel_map* m, const double* centre, double size,             \
+                                                  double threshold, int target, double radius, R* spheres, int cap,         \
+                                                  int32_t* count, int32_t* workspace, void* stream) {                       \
+    return voxel_local_spheres_impl<R>(m, centre, size, threshold, target, radius, spheres, cap, count, workspace, stream); \
+  }
+
+SE3MPC_DEFINE_VOXEL_API(f32, float)
+SE3MPC_DEFINE_VOXEL_API(f64, double)

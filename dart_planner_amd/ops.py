@@ -65,6 +65,9 @@ class TorchBackend:
     def to_host(self, a) -> np.ndarray:
         return a.detach().cpu().numpy()
 
+    def from_host(self, a: np.ndarray):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
+
 
 class Ops:
     """Shape-checked calls into libse3mpc for one array backend."""

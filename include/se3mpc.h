@@ -245,6 +245,74 @@ int se3mpc_spheres_from_grid_f64(const double* positions, const double* occupanc
 int se3mpc_transpose_f32(int rows, int cols, const float* in, int ld_in, float* out, int ld_out, void* stream);
 int se3mpc_transpose_f64(int rows, int cols, const double* in, int ld_in, double* out, int ld_out, void* stream);
 
+/* ------------------------------------------------------------------ voxel map (obstacle source)
+ * Device-resident counterpart of ExplicitGeometricMapper (src/dart_planner/perception/explicit_geometric_mapper.py,
+ * "mapper.py" below): the sparse voxel dict (mapper.py:74-76) becomes an open-addressing hash table in HBM owned by
+ * the caller.  A voxel index (ix, iy, iz) = floor(position / resolution) (mapper.py:93-96, float64) is packed as
+ * three 21-bit fields (|index| < 2^20: +-200 km at 0.2 m); SE3MPC_VOXEL_EMPTY marks a free slot.  Positions outside
+ * that range read as unknown (prior).  All entry points are stream-ordered and allocate nothing. */
+#define SE3MPC_VOXEL_EMPTY 0xFFFFFFFFFFFFFFFFull
+#define SE3MPC_VOXEL_MAX_CELLS 1024   /* cells per axis of a local grid (axis tables staged in LDS) */
+
+typedef struct se3mpc_voxel_map {
+  uint64_t* keys;      /* [capacity] packed voxel index                                   */
+  double* prob;        /* [capacity] occupancy_probability (mapper.py:31)                 */
+  int32_t* count;      /* [capacity] observation_count     (mapper.py:33)                 */
+  int32_t capacity;    /* power of two, >= 64; keep the load factor under ~0.7            */
+  int32_t reserved;
+  double resolution;   /* voxel edge in metres (mapper.py:66, default 0.2)                */
+  double prior;        /* occupancy of unknown space: prob_prior = 0.5 (mapper.py:83)     */
+} se3mpc_voxel_map;
+
+/* keys = EMPTY, prob = prior, count = 0. */
+int se3mpc_voxel_clear(const se3mpc_voxel_map* m, void* stream);
+/* Create-or-overwrite M voxels (ijk: [M][3] voxel indices; prob: [M], or NULL for `value` everywhere; count_in:
+ * [M] observation counts, or NULL to leave counts untouched) -- what add_obstacle does with 0.9
+ * (mapper.py:424-447), how a host-built map is uploaded and how a table is re-hashed into a larger one.
+ * *failed (device) is incremented per voxel that could not be stored (table full / index out of range). */
+int se3mpc_voxel_insert(const se3mpc_voxel_map* m, const int32_t* ijk, const double* prob, double value,
+                        const int32_t* count_in, int M, int32_t* failed, void* stream);
+/* update_map (mapper.py:102-153) for M observations in their order: origin [M][3], direction [M][3] (UNIT vectors:
+ * the caller normalises, as mapper.py:265 does), distance [M] = min(hit_distance or max_range, map max_range)
+ * (:111-112), hit [M] = 1 when the observation carries a hit distance (the ray's last voxel is then updated with
+ * like_hit = prob_hit, every other voxel with like_miss = 1 - prob_miss, :319-323).  Voxels are walked with the
+ * reference's DDA (:251-312) and updated ray after ray, because the clamped Bayesian update (:325-337) does not
+ * commute.  Workspace: ray_keys device uint64 [M][max_len], ray_len device int32 [M]; max_len >=
+ * 3 * ceil(distance / resolution) + 8 never truncates.  stats: device int32[4] = {voxel updates, voxels that
+ * could not be stored, truncated rays, 0} (reset by the call). */
+int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
+                             const double* distance, const int32_t* hit, int M, double like_hit, double like_miss,
+                             uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* stats, void* stream);
+/* Compact the occupied slots (order unspecified): ijk_out [capacity][3], prob_out / count_out [capacity] (may be
+ * NULL), *n_out = number of voxels (the caller zeroes nothing: the function resets *n_out itself). */
+int se3mpc_voxel_export(const se3mpc_voxel_map* m, int32_t* ijk_out, double* prob_out, int32_t* count_out,
+                        int32_t* n_out, void* stream);
+/* query_occupancy_batch (mapper.py:155-183): positions [M][3] -> occupancy [M] (float64 as stored). */
+int se3mpc_voxel_query_f32(const se3mpc_voxel_map* m, const float* positions, int M, double* occupancy, void* stream);
+int se3mpc_voxel_query_f64(const se3mpc_voxel_map* m, const double* positions, int M, double* occupancy, void* stream);
+/* is_trajectory_safe (mapper.py:185-219, :339-353) for B trajectories at once: trajectory b = N rows of 3 at
+ * P + b * stride (elements; stride = 9N reads the P block of se3mpc_solve_*'s X directly).  Each position is
+ * checked with its 6 axis neighbours at +-margin; safe[b] = 1/0, first[b] = index of the first colliding
+ * position or -1.  One wavefront per trajectory. */
+int se3mpc_voxel_trajectory_safe_f32(const se3mpc_voxel_map* m, const float* P, int B, int N, long long stride,
+                                     double margin, double threshold, int32_t* safe, int32_t* first, void* stream);
+int se3mpc_voxel_trajectory_safe_f64(const se3mpc_voxel_map* m, const double* P, int B, int N, long long stride,
+                                     double margin, double threshold, int32_t* safe, int32_t* first, void* stream);
+/* get_local_occupancy_grid (mapper.py:221-248) fused with the grid -> sphere selection of
+ * cloud/main_improved_threelayer.py:387-398 / tests/test_se3_mpc_with_mapper.py:29-33, without materialising the
+ * grid: n = int(size / resolution) cells per axis at linspace(centre - size/2, centre + size/2, n) (numpy's
+ * i * step + start, last = stop), cell order (iz, ix, iy) with iy fastest, occupied = occupancy > threshold,
+ * step = max(1, n_occupied // target), every step-th occupied cell becomes (x, y, z, radius).
+ * centre: HOST pointer to 3 doubles.  spheres: [cap][4]; count: device int32[2] = {spheres written, n_occupied};
+ * workspace: device int32[se3mpc_voxel_local_workspace(n)]. */
+int se3mpc_voxel_local_workspace(int cells_per_axis);
+int se3mpc_voxel_local_spheres_f32(const se3mpc_voxel_map* m, const double* centre, double size, double threshold,
+                                   int target, double radius, float* spheres, int cap, int32_t* count,
+                                   int32_t* workspace, void* stream);
+int se3mpc_voxel_local_spheres_f64(const se3mpc_voxel_map* m, const double* centre, double size, double threshold,
+                                   int target, double radius, double* spheres, int cap, int32_t* count,
+                                   int32_t* workspace, void* stream);
+
 /* ------------------------------------------------------------------ problem layout: [b][row]
  * The batched solve: replaces _solve_se3_mpc (planner.py:230-280) = cold start (or a caller
  * x0), box, scipy.optimize.minimize(method="L-BFGS-B", jac=..., bounds=..., maxiter, gtol,

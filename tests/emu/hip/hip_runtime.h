@@ -169,3 +169,10 @@ inline unsigned long long atomicMin(unsigned long long* p, unsigned long long v)
   if (v < old) *p = v;
   return old;
 }
+inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long expect, unsigned long long desired) {
+  unsigned long long old = *p;
+  if (old == expect) *p = desired;
+  return old;
+}
+inline int atomicAdd(int* p, int v) { int old = *p; *p = old + v; return old; }
+inline void __threadfence() {}

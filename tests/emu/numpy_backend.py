@@ -32,6 +32,9 @@ class NumpyBackend:
     def to_host(self, a):
         return a
 
+    def from_host(self, a):
+        return np.ascontiguousarray(a).copy()
+
 
 class TorchCpuBackend:
     """CPU torch tensors + the emulated library: lets the CPU suite drive the planner's real host
@@ -66,3 +69,6 @@ class TorchCpuBackend:
 
     def to_host(self, a):
         return a.numpy()
+
+    def from_host(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a).copy())
