@@ -86,13 +86,17 @@ __device__ __forceinline__ int vox_find(const VoxDev& d, unsigned long long key)
   return -1;
 }
 
-// slot of `key`, claiming a free one if it is new; -1 = table full
-__device__ __forceinline__ int vox_find_or_claim(const VoxDev& d, unsigned long long key) {
+// slot of `key`, claiming a free one if it is new (`created` is then set); -1 = table full
+__device__ __forceinline__ int vox_find_or_claim(const VoxDev& d, unsigned long long key, bool& created) {
   uint32_t h = vox_hash(d, key);
+  created = false;
   for (uint32_t n = 0; n <= d.mask; ++n) {
     unsigned long long k = d.keys[h];
-    if (k == kVoxEmpty) k = atomicCAS(&d.keys[h], kVoxEmpty, key);
-    if (k == kVoxEmpty || k == key) return (int)h;
+    if (k == kVoxEmpty) {
+      k = atomicCAS(&d.keys[h], kVoxEmpty, key);
+      if (k == kVoxEmpty) { created = true; return (int)h; }
+    }
+    if (k == key) return (int)h;
     h = (h + 1u) & d.mask;
   }
   return -1;
@@ -126,12 +130,14 @@ voxel_insert_kernel(VoxDev d, const int32_t* __restrict__ ijk, const double* __r
   if (i >= M) return;
   unsigned long long key;
   int s = -1;
-  if (vox_pack(ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2], key)) s = vox_find_or_claim(d, key);
+  bool created = false;
+  if (vox_pack(ijk[3 * i], ijk[3 * i + 1], ijk[3 * i + 2], key)) s = vox_find_or_claim(d, key, created);
   if (s >= 0) {
     d.prob[s] = prob != nullptr ? prob[i] : value;
     if (count_in != nullptr) d.count[s] = count_in[i];
+    if (created && failed != nullptr) atomicAdd(&failed[1], 1);
   } else if (failed != nullptr) {
-    atomicAdd(failed, 1);
+    atomicAdd(&failed[0], 1);
   }
 }
 
@@ -307,56 +313,50 @@ voxel_trace_kernel(VoxDev d, const double* __restrict__ origin, const double* __
   const int ray = blockIdx.x * blockDim.x + threadIdx.x;
   if (ray >= M) return;
   const double res = d.res, dist = distance[ray];
-  double start[3], dir[3], t_max[3], t_delta[3];
-  long long cur[3], endv[3];
-  int step[3];
-  bool ok = true;
-  for (int a = 0; a < 3; ++a) {
-    start[a] = origin[3 * ray + a];
-    dir[a] = direction[3 * ray + a];
-    const double e = start[a] + dir[a] * dist;                 // mapper.py:268
-    const double c0 = floor(start[a] / res), c1 = floor(e / res);
-    ok = ok && fabs(c0) < 9.0e15 && fabs(c1) < 9.0e15;         // finite and exactly representable
-    cur[a] = ok ? (long long)c0 : 0;
-    endv[a] = ok ? (long long)c1 : 0;
-  }
+  // per-axis state in named scalars: a dynamically indexed private array would live in scratch memory
+  const double s0 = origin[3 * ray], s1 = origin[3 * ray + 1], s2 = origin[3 * ray + 2];
+  const double d0 = direction[3 * ray], d1 = direction[3 * ray + 1], d2 = direction[3 * ray + 2];
+  const double f0 = floor(s0 / res), f1 = floor(s1 / res), f2 = floor(s2 / res);
+  const double g0 = floor((s0 + d0 * dist) / res), g1 = floor((s1 + d1 * dist) / res), g2 = floor((s2 + d2 * dist) / res);   // :268-270
+  // both end voxels inside the packable range <=> every voxel of the walk is (it stays in their bounding box); a ray
+  // that leaves the range cannot be stored and is dropped as a whole (counted in stats[1])
+  const double lim = (double)(kVoxBias - 1);
+  const bool ok = fabs(f0) <= lim && fabs(f1) <= lim && fabs(f2) <= lim && fabs(g0) <= lim && fabs(g1) <= lim && fabs(g2) <= lim;
   unsigned long long* out = ray_keys + (size_t)ray * (size_t)max_len;
   int len = 0;
   bool truncated = false;
   if (ok) {
-    for (int a = 0; a < 3; ++a) {
-      step[a] = endv[a] > cur[a] ? 1 : (endv[a] < cur[a] ? -1 : 0);
-      if (step[a] != 0) {
-        t_delta[a] = res / fabs(dir[a]);                                         // :285-291
-        const double boundary = (double)(cur[a] + (step[a] > 0 ? 1 : 0)) * res;  // :294-296
-        t_max[a] = fabs((boundary - start[a]) / dir[a]);                         // :298-304
-      } else {
-        t_delta[a] = INFINITY;
-        t_max[a] = INFINITY;
-      }
-    }
-    auto emit = [&]() {
-      if (len < max_len) {
-        unsigned long long key = kVoxEmpty;
-        const long long lim = kVoxBias;
-        if (cur[0] >= -lim && cur[0] < lim && cur[1] >= -lim && cur[1] < lim && cur[2] >= -lim && cur[2] < lim)
-          vox_pack((int)cur[0], (int)cur[1], (int)cur[2], key);
-        out[len++] = key;
-      } else {
-        truncated = true;
-      }
-    };
-    emit();
+    int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+    const int e0 = (int)g0, e1 = (int)g1, e2 = (int)g2;
+    const int st0 = e0 > c0 ? 1 : (e0 < c0 ? -1 : 0), st1 = e1 > c1 ? 1 : (e1 < c1 ? -1 : 0), st2 = e2 > c2 ? 1 : (e2 < c2 ? -1 : 0);
+    // t_delta (:285-291), first boundary (:294-296), t_max (:298-304)
+    const double td0 = st0 ? res / fabs(d0) : INFINITY, td1 = st1 ? res / fabs(d1) : INFINITY, td2 = st2 ? res / fabs(d2) : INFINITY;
+    double tm0 = st0 ? fabs(((double)(c0 + (st0 > 0 ? 1 : 0)) * res - s0) / d0) : INFINITY;
+    double tm1 = st1 ? fabs(((double)(c1 + (st1 > 0 ? 1 : 0)) * res - s1) / d1) : INFINITY;
+    double tm2 = st2 ? fabs(((double)(c2 + (st2 > 0 ? 1 : 0)) * res - s2) / d2) : INFINITY;
+    // the packed key moves with the walk: one signed increment per axis step (the walk may overshoot the end voxel
+    // by rounding, so it is bounded by `total <= dist` exactly as the reference's loop is, and by the range)
+    unsigned long long key = 0;
+    vox_pack(c0, c1, c2, key);
+    const unsigned long long k0 = (unsigned long long)((long long)st0 << 42), k1 = (unsigned long long)((long long)st1 << 21),
+                             k2 = (unsigned long long)(long long)st2;
+    out[len++] = key;
     double total = 0.0;
-    while ((cur[0] != endv[0] || cur[1] != endv[1] || cur[2] != endv[2]) && total <= dist && !truncated) {   // :307
-      int axis = 0;                                             // np.argmin: first minimum
-      if (t_max[1] < t_max[axis]) axis = 1;
-      if (t_max[2] < t_max[axis]) axis = 2;
-      cur[axis] += step[axis];
-      total = t_max[axis];
-      t_max[axis] += t_delta[axis];
-      emit();
+    const int ilim = (int)kVoxBias - 1;
+    while ((c0 != e0 || c1 != e1 || c2 != e2) && total <= dist) {          // :307
+      const bool a0 = tm0 <= tm1 && tm0 <= tm2;                           // np.argmin(t_max): the first minimum
+      const bool a1 = !a0 && tm1 <= tm2;
+      const bool a2 = !a0 && !a1;
+      total = a0 ? tm0 : (a1 ? tm1 : tm2);
+      tm0 = a0 ? tm0 + td0 : tm0; tm1 = a1 ? tm1 + td1 : tm1; tm2 = a2 ? tm2 + td2 : tm2;
+      c0 += a0 ? st0 : 0; c1 += a1 ? st1 : 0; c2 += a2 ? st2 : 0;
+      key += a0 ? k0 : (a1 ? k1 : k2);
+      if (len >= max_len) { truncated = true; break; }
+      const bool inside = c0 >= -ilim - 1 && c0 <= ilim && c1 >= -ilim - 1 && c1 <= ilim && c2 >= -ilim - 1 && c2 <= ilim;
+      out[len++] = inside ? key : kVoxEmpty;
     }
+  } else if (stats != nullptr) {
+    atomicAdd(&stats[1], 1);
   }
   ray_len[ray] = len;
   if (truncated && stats != nullptr) atomicAdd(&stats[2], 1);
@@ -371,35 +371,59 @@ __device__ __forceinline__ double vox_bayes(double p, double like) {
   return fmin(fmax(p, 0.01), 0.99);
 }
 
+// Slot resolution for every walked voxel, fully parallel (creating a voxel does not depend on the order): the packed
+// key in ray_keys[ray][i] is replaced in place by its table slot (or kVoxEmpty when it cannot be stored).
+__global__ void __launch_bounds__(256)
+voxel_resolve_kernel(VoxDev d, unsigned long long* __restrict__ ray_keys, const int32_t* __restrict__ ray_len, int M, int max_len,
+                     int32_t* __restrict__ stats) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= (long long)M * max_len) return;
+  const int ray = (int)(j / max_len), i = (int)(j - (long long)ray * max_len);
+  if (i >= ray_len[ray]) return;
+  const unsigned long long key = ray_keys[j];
+  bool created = false;
+  const int s = key == kVoxEmpty ? -1 : vox_find_or_claim(d, key, created);
+  ray_keys[j] = s < 0 ? kVoxEmpty : (unsigned long long)s;
+  if (stats != nullptr) {
+    if (s < 0) atomicAdd(&stats[1], 1);
+    if (created) atomicAdd(&stats[3], 1);
+  }
+}
+
 // The updates of update_map (mapper.py:114-141) in observation order: the clamped Bayesian update does not commute,
-// so rays are applied one after another; the voxels of ONE ray are distinct and are updated in parallel by the
-// 1024 lanes of a single workgroup.  Between rays: agent-scope fence (so the next ray's loads see this ray's
-// stores through L2) and a workgroup barrier.
+// so rays are applied one after another; the voxels of ONE ray are distinct and are updated in parallel by the lanes
+// of a single workgroup (a workgroup barrier orders one ray's stores before the next ray's loads: same CU, same
+// L1).  The next ray's length, hit flag and first slots are fetched before the barrier, so the only exposed latency
+// per ray is one probability round trip.
 __global__ void __launch_bounds__(1024)
-voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_keys, const int32_t* __restrict__ ray_len,
+voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_slots, const int32_t* __restrict__ ray_len,
                    const int32_t* __restrict__ hit, int M, int max_len, double like_hit, double like_miss,
                    int32_t* __restrict__ stats) {
-  int updates = 0, lost = 0;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  int updates = 0;
+  int len_n = ray_len[0], hit_n = hit[0];
+  unsigned long long slot_n = tid < len_n ? ray_slots[tid] : kVoxEmpty;
   for (int ray = 0; ray < M; ++ray) {
-    const int len = ray_len[ray];
-    const bool has_hit = hit[ray] != 0;
-    const unsigned long long* keys = ray_keys + (size_t)ray * (size_t)max_len;
-    for (int i = threadIdx.x; i < len; i += blockDim.x) {
-      const unsigned long long key = keys[i];
-      const int s = key == kVoxEmpty ? -1 : vox_find_or_claim(d, key);
-      if (s < 0) { ++lost; continue; }
+    const int len = len_n;
+    const bool has_hit = hit_n != 0;
+    unsigned long long sl = slot_n;
+    const unsigned long long* slots = ray_slots + (size_t)ray * (size_t)max_len;
+    if (ray + 1 < M) {
+      len_n = ray_len[ray + 1];
+      hit_n = hit[ray + 1];
+      slot_n = tid < len_n ? slots[max_len + tid] : kVoxEmpty;
+    }
+    for (int i = tid; i < len; i += nthr) {
+      if (i != tid) sl = slots[i];
+      if (sl == kVoxEmpty) continue;
       const bool endpoint = (i == len - 1) && has_hit;                    // :121-123
-      d.prob[s] = vox_bayes(d.prob[s], endpoint ? like_hit : like_miss);
-      d.count[s] += 1;
+      d.prob[sl] = vox_bayes(d.prob[sl], endpoint ? like_hit : like_miss);
+      d.count[sl] += 1;
       ++updates;
     }
-    __threadfence();
     __syncthreads();
   }
-  if (stats != nullptr) {
-    if (updates) atomicAdd(&stats[0], updates);
-    if (lost) atomicAdd(&stats[1], lost);
-  }
+  if (stats != nullptr && updates) atomicAdd(&stats[0], updates);
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -517,7 +541,7 @@ extern "C" int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double*
   VoxDev d;
   int rc = make_vox_dev(m, d);
   if (rc) return rc;
-  if (M < 0 || max_len < 1) return SE3MPC_ERR_SHAPE;
+  if (M < 0 || max_len < 1 || (long long)M * max_len > (1ll << 31)) return SE3MPC_ERR_SHAPE;
   if (!(like_hit > 0.0 && like_hit < 1.0 && like_miss > 0.0 && like_miss < 1.0)) return SE3MPC_ERR_PARAM;
   hipStream_t s = (hipStream_t)stream;
   if (stats != nullptr && hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), s) != hipSuccess)
@@ -527,6 +551,11 @@ extern "C" int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double*
   hipLaunchKernelGGL(voxel_trace_kernel, dim3(grid_for(M, 64)), dim3(64), 0, s, d, origin, direction, distance, M,
                      reinterpret_cast<unsigned long long*>(ray_keys), ray_len, max_len, stats);
   rc = launch_status("se3mpc_voxel_update_rays(trace)");
+  if (rc) return rc;
+  const long long recs = (long long)M * max_len;
+  hipLaunchKernelGGL(voxel_resolve_kernel, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, s, d,
+                     reinterpret_cast<unsigned long long*>(ray_keys), ray_len, M, max_len, stats);
+  rc = launch_status("se3mpc_voxel_update_rays(resolve)");
   if (rc) return rc;
   int threads = 64;                                     // one lane per voxel of the longest possible ray, up to 1024
   while (threads < max_len && threads < 1024) threads *= 2;

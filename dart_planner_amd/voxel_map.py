@@ -91,9 +91,11 @@ class DeviceVoxelMap:
         self._zero_scratch()
         self.lib.voxel("insert", self.desc, self.be.ptr(d_ijk), self.be.ptr(d_prob), float(value if value is not None else 0.0),
                        self.be.ptr(d_cnt), len(ijk), self.be.ptr(failed), self.be.stream())
-        if int(self.be.to_host(failed)[0]) != 0:
+        f = self.be.to_host(failed)
+        if int(f[0]) != 0:
             raise RuntimeError("voxel table full")
-        self._n = None
+        if self._n is not None:
+            self._n += int(f[1])
 
     def _zero_scratch(self) -> None:
         z = self._scratch
@@ -184,5 +186,6 @@ class DeviceVoxelMap:
         st = self.be.to_host(stats)
         if int(st[1]) or int(st[2]):
             raise RuntimeError(f"voxel update dropped work: {int(st[1])} voxels not stored, {int(st[2])} rays truncated")
-        self._n = None
+        if self._n is not None:
+            self._n += int(st[3])
         return int(st[0]), len(self)

@@ -269,7 +269,8 @@ int se3mpc_voxel_clear(const se3mpc_voxel_map* m, void* stream);
 /* Create-or-overwrite M voxels (ijk: [M][3] voxel indices; prob: [M], or NULL for `value` everywhere; count_in:
  * [M] observation counts, or NULL to leave counts untouched) -- what add_obstacle does with 0.9
  * (mapper.py:424-447), how a host-built map is uploaded and how a table is re-hashed into a larger one.
- * *failed (device) is incremented per voxel that could not be stored (table full / index out of range). */
+ * failed: device int32[2], incremented (not reset): [0] per voxel that could not be stored (table full / index
+ * out of range), [1] per voxel that did not exist before. */
 int se3mpc_voxel_insert(const se3mpc_voxel_map* m, const int32_t* ijk, const double* prob, double value,
                         const int32_t* count_in, int M, int32_t* failed, void* stream);
 /* update_map (mapper.py:102-153) for M observations in their order: origin [M][3], direction [M][3] (UNIT vectors:
@@ -279,7 +280,7 @@ int se3mpc_voxel_insert(const se3mpc_voxel_map* m, const int32_t* ijk, const dou
  * reference's DDA (:251-312) and updated ray after ray, because the clamped Bayesian update (:325-337) does not
  * commute.  Workspace: ray_keys device uint64 [M][max_len], ray_len device int32 [M]; max_len >=
  * 3 * ceil(distance / resolution) + 8 never truncates.  stats: device int32[4] = {voxel updates, voxels that
- * could not be stored, truncated rays, 0} (reset by the call). */
+ * could not be stored, truncated rays, voxels created} (reset by the call). */
 int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
                              const double* distance, const int32_t* hit, int M, double like_hit, double like_miss,
                              uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* stats, void* stream);
