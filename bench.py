@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the p95 solve-latency leg")
+    ap.add_argument("--no-obstacle-source", action="store_true", help="skip the voxel-map leg (mapper -> planner obstacles)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--steps-per-launch", type=int, default=64,
                     help="independent 8192-rollout steps issued as ONE multi-batch kernel launch (1 = one launch per step)")
@@ -245,6 +246,7 @@ def main():
         del graph
 
     solve_stats = None if a.no_solve else solve_leg(torch, ops, dev, B, N, rank, world)
+    voxel_stats = None if (a.no_obstacle_source or rank != 0) else obstacle_source_leg(torch, ops, dev)
 
     if rank == 0:
         r = results["primary"]
@@ -282,6 +284,8 @@ def main():
                                     "keys_valid": q["keys_valid"]}
         if solve_stats is not None:
             res["solve"] = solve_stats
+        if voxel_stats is not None:
+            res["obstacle_source"] = voxel_stats
         if a.sweep:
             res["sweep"] = sweep(torch, ops, prm, dev, N)
         if cpu_stats is not None:
@@ -349,6 +353,43 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
                         "mean_nfev": float(info["nfev"].mean()), "mean_nit": float(info["nit"].mean()),
                         "rollouts_inside_solves_per_s": float(agg.item() * info["nfev"].mean())}
     return out
+
+
+def obstacle_source_leg(torch, ops, dev):
+    """The caller side of the path at the sizes of the reference's planning cycle
+    (cloud/main_improved_threelayer.py:204-209, 381-398): one 360-ray scan into the device voxel map, then the
+    20 m local grid at 0.2 m (10^6 cells) -> 20 obstacle spheres, then the safety check of 8192 30-step plans.
+    Device-event times of the kernels with resident inputs; seeded synthetic scene."""
+    from dart_planner_amd.perception.explicit_geometric_mapper import ExplicitGeometricMapper
+    rng = np.random.default_rng(5)
+    m = ExplicitGeometricMapper(resolution=0.2, max_range=50.0, ops=ops)
+    for _ in range(8):
+        m.add_obstacle(rng.uniform(-8, 8, 3) + [0, 0, 2], float(rng.uniform(0.5, 1.5)))
+    n = 360
+    ang = 2 * np.pi * np.arange(n) / n
+    dirs = np.stack([np.cos(ang), np.sin(ang), np.zeros(n)], 1)
+    hit = rng.random(n) < 0.1
+    dist = np.where(hit, rng.uniform(2.0, 20.0, n), 50.0)
+    org = np.tile([0.3, 0.1, 2.0], (n, 1))
+
+    def dev_ms(fn, reps):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+
+    m.map.update_rays(org, dirs, dist, hit.astype(np.int32))          # first scan: creates the voxels, sizes the table
+    upd = dev_ms(lambda: m.map.update_rays(org, dirs, dist, hit.astype(np.int32)), 5)
+    centre = np.array([0.3, 0.1, 2.0])
+    grid = dev_ms(lambda: m.map.local_spheres(centre, 20.0, 0.6, 20, 1.0), 20)
+    plans = torch.rand(8192, 30, 3, device=dev, dtype=torch.float32) * 20 - 10
+    safe = dev_ms(lambda: m.map.trajectories_safe(plans, margin=1.0, threshold=0.6), 20)
+    return {"what": "device voxel map (reference: ExplicitGeometricMapper's dict walk), float64 index arithmetic, bit-exact",
+            "update_map_360_rays_ms": upd, "local_grid_1e6_cells_to_spheres_ms": grid, "trajectory_safe_8192x30_ms": safe,
+            "voxels": len(m.map), "table_capacity": m.map.capacity}
 
 
 def profiled_traffic(B, N, S):

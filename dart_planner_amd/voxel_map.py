@@ -5,7 +5,7 @@
 ``dart_planner_amd.perception.explicit_geometric_mapper.ExplicitGeometricMapper``.
 
 The table (packed keys, float64 probabilities, int32 observation counts) lives in HBM as three tensors of the
-array backend; it is re-hashed into a larger one before an operation that could push the load factor over 1/2.
+array backend; it is re-hashed into a larger one before an operation that could fill it (see ``reserve``).
 There is no CPU path: without the HIP library every call raises."""
 from __future__ import annotations
 
@@ -17,7 +17,6 @@ import numpy as np
 from .capi import VoxelMapDesc
 from .ops import Ops
 
-LOAD_NUM, LOAD_DEN = 1, 2          # keep n_voxels <= capacity / 2
 
 
 class DeviceVoxelMap:
@@ -69,12 +68,13 @@ class DeviceVoxelMap:
         return k[order], np.array(self.be.to_host(prob)[:n])[order], np.array(self.be.to_host(cnt)[:n], dtype=np.int64)[order]
 
     def reserve(self, extra: int) -> None:
-        """Make room for `extra` more voxels at load factor <= 1/2 (re-hash into a larger table if needed)."""
-        need = (len(self) + int(extra)) * LOAD_DEN // LOAD_NUM
-        if need <= self.capacity:
+        """Make sure `extra` more voxels cannot overflow the table (voxels + extra <= 85 % of the capacity); when it
+        has to grow, re-hash into a table twice that bound, so a steady stream of same-sized updates re-hashes rarely."""
+        need = len(self) + int(extra)
+        if need * 100 <= self.capacity * 85:
             return
         k, p, c = self.items()
-        self._alloc(self._pow2(need))
+        self._alloc(self._pow2(2 * need))
         self.lib.voxel("clear", self.desc, self.be.stream())
         self._n = 0
         if len(k):

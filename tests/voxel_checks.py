@@ -111,7 +111,7 @@ def check_edges(ops):
     ijk = np.stack(np.meshgrid(np.arange(-10, 10), np.arange(0, 25), np.arange(-5, 5), indexing="ij"), -1).reshape(-1, 3)
     m.map.insert(ijk, prob=np.linspace(0.0, 1.0, len(ijk)))
     keys, prob, _ = m.map.items()
-    assert len(keys) == len(ijk) == len(m.map) and m.map.capacity >= 2 * len(ijk)
+    assert len(keys) == len(ijk) == len(m.map) and m.map.capacity * 85 >= 100 * len(ijk)
     order = np.lexsort((ijk[:, 2], ijk[:, 1], ijk[:, 0]))
     assert np.array_equal(keys, ijk[order]) and np.array_equal(prob, np.linspace(0.0, 1.0, len(ijk))[order])
     # C-ABI statuses
