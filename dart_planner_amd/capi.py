@@ -129,7 +129,8 @@ _VOXEL_TYPED_API = {
 _VOXEL_PLAIN_API = {
     "se3mpc_voxel_clear": (C.c_int, [_VP, _P]),
     "se3mpc_voxel_insert": (C.c_int, [_VP, _P, _P, _D, _P, _I, _P, _P]),
-    "se3mpc_voxel_update_rays": (C.c_int, [_VP, _P, _P, _P, _P, _I, _D, _D, _P, _P, _I, _P, _P]),
+    "se3mpc_voxel_update_rays": (C.c_int, [_VP, _P, _P, _P, _P, _I, _D, _D, _P, _P, _I, _P, _P, _P, _P]),
+    "se3mpc_voxel_update_row_words": (C.c_longlong, [_I, _I]),
     "se3mpc_voxel_export": (C.c_int, [_VP, _P, _P, _P, _P, _P]),
     "se3mpc_voxel_local_workspace": (C.c_int, [_I]),
 }
@@ -254,6 +255,9 @@ class Library:
 
     def voxel_local_workspace(self, cells_per_axis: int) -> int:
         return self._dll.se3mpc_voxel_local_workspace(cells_per_axis)
+
+    def voxel_update_row_words(self, M: int, max_len: int) -> int:
+        return self._dll.se3mpc_voxel_update_row_words(M, max_len)
 
     def _check(self, name: str, rc: int) -> None:
         if rc != 0:

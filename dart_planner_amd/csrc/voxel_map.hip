@@ -359,7 +359,10 @@ voxel_trace_kernel(VoxDev d, const double* __restrict__ origin, const double* __
     atomicAdd(&stats[1], 1);
   }
   ray_len[ray] = len;
-  if (truncated && stats != nullptr) atomicAdd(&stats[2], 1);
+  if (stats != nullptr) {
+    if (len) atomicAdd(&stats[0], len);                      // walked voxels (those that cannot be stored are in stats[1])
+    if (truncated) atomicAdd(&stats[2], 1);
+  }
 }
 
 // _bayesian_update (mapper.py:314-337)
@@ -371,59 +374,76 @@ __device__ __forceinline__ double vox_bayes(double p, double like) {
   return fmin(fmax(p, 0.01), 0.99);
 }
 
-// Slot resolution for every walked voxel, fully parallel (creating a voxel does not depend on the order): the packed
-// key in ray_keys[ray][i] is replaced in place by its table slot (or kVoxEmpty when it cannot be stored).
+// Slot resolution for every walked voxel, fully parallel (creating a voxel does not depend on the order).  Record
+// j = (ray, i) finds or claims its table slot (written back in place of the key) and files its ray into the slot's
+// "row": two bit sets over the rays of this call -- which rays touch the voxel, and which of those end in it with a
+// hit.  The row of a slot is the one of the first record that reaches it (slot_rows[slot] = j + 1 by atomicCAS: no
+// counter, no waiting).  Rows and slot_rows are all-zero between calls.
 __global__ void __launch_bounds__(256)
-voxel_resolve_kernel(VoxDev d, unsigned long long* __restrict__ ray_keys, const int32_t* __restrict__ ray_len, int M, int max_len,
-                     int32_t* __restrict__ stats) {
+voxel_resolve_kernel(VoxDev d, unsigned long long* __restrict__ ray_keys, const int32_t* __restrict__ ray_len,
+                     const int32_t* __restrict__ hit, int M, int max_len, int32_t* __restrict__ slot_rows,
+                     unsigned long long* __restrict__ row_bits, int W, int32_t* __restrict__ stats) {
+  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool in_range = j < (long long)M * max_len;
+  const int ray = in_range ? (int)(j / max_len) : 0, i = in_range ? (int)(j - (long long)ray * max_len) : 0;
+  const int len = in_range ? ray_len[ray] : 0;
+  const bool live = in_range && i < len;
+  bool created = false, lost = false;
+  if (live) {
+    const unsigned long long key = ray_keys[j];
+    const int s = key == kVoxEmpty ? -1 : vox_find_or_claim(d, key, created);
+    ray_keys[j] = s < 0 ? kVoxEmpty : (unsigned long long)s;
+    lost = s < 0;
+    if (s >= 0) {
+      int row = atomicCAS(&slot_rows[s], 0, (int)j + 1);
+      if (row == 0) row = (int)j + 1;
+      unsigned long long* bits = row_bits + (size_t)(row - 1) * (size_t)(2 * W);
+      const unsigned long long bit = 1ull << (ray & 63);
+      atomicOr(&bits[ray >> 6], bit);
+      if (i == len - 1 && hit[ray] != 0) atomicOr(&bits[W + (ray >> 6)], bit);        // mapper.py:121-123
+    }
+  }
+  // one atomic per wavefront for the counters (same-address atomics serialise)
+  const int n_created = __builtin_popcountll(wave_ballot(created)), n_lost = __builtin_popcountll(wave_ballot(lost));
+  if (stats != nullptr && lane_id() == 0) {
+    if (n_created) atomicAdd(&stats[3], n_created);
+    if (n_lost) atomicAdd(&stats[1], n_lost);
+  }
+}
+
+// The updates of update_map (mapper.py:114-141): the clamped Bayesian update does not commute, so every voxel must
+// see its observations in observation order -- but voxels are independent of each other.  The record that owns a
+// voxel's row walks the row's bits in ray order (a ray visits a voxel at most once) and applies hit / pass-through
+// updates one after another; all touched voxels proceed in parallel, the longest chain is the sensor's own voxel
+// (every ray).  The row and the slot's row id are cleared on the way out.
+__global__ void __launch_bounds__(256)
+voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_slots, const int32_t* __restrict__ ray_len, int M,
+                   int max_len, int32_t* __restrict__ slot_rows, unsigned long long* __restrict__ row_bits, int W,
+                   double like_hit, double like_miss) {
   const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= (long long)M * max_len) return;
   const int ray = (int)(j / max_len), i = (int)(j - (long long)ray * max_len);
   if (i >= ray_len[ray]) return;
-  const unsigned long long key = ray_keys[j];
-  bool created = false;
-  const int s = key == kVoxEmpty ? -1 : vox_find_or_claim(d, key, created);
-  ray_keys[j] = s < 0 ? kVoxEmpty : (unsigned long long)s;
-  if (stats != nullptr) {
-    if (s < 0) atomicAdd(&stats[1], 1);
-    if (created) atomicAdd(&stats[3], 1);
-  }
-}
-
-// The updates of update_map (mapper.py:114-141) in observation order: the clamped Bayesian update does not commute,
-// so rays are applied one after another; the voxels of ONE ray are distinct and are updated in parallel by the lanes
-// of a single workgroup (a workgroup barrier orders one ray's stores before the next ray's loads: same CU, same
-// L1).  The next ray's length, hit flag and first slots are fetched before the barrier, so the only exposed latency
-// per ray is one probability round trip.
-__global__ void __launch_bounds__(1024)
-voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_slots, const int32_t* __restrict__ ray_len,
-                   const int32_t* __restrict__ hit, int M, int max_len, double like_hit, double like_miss,
-                   int32_t* __restrict__ stats) {
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  int updates = 0;
-  int len_n = ray_len[0], hit_n = hit[0];
-  unsigned long long slot_n = tid < len_n ? ray_slots[tid] : kVoxEmpty;
-  for (int ray = 0; ray < M; ++ray) {
-    const int len = len_n;
-    const bool has_hit = hit_n != 0;
-    unsigned long long sl = slot_n;
-    const unsigned long long* slots = ray_slots + (size_t)ray * (size_t)max_len;
-    if (ray + 1 < M) {
-      len_n = ray_len[ray + 1];
-      hit_n = hit[ray + 1];
-      slot_n = tid < len_n ? slots[max_len + tid] : kVoxEmpty;
+  const unsigned long long sl = ray_slots[j];
+  if (sl == kVoxEmpty || slot_rows[sl] != (int)j + 1) return;            // not stored, or another record owns the row
+  unsigned long long* bits = row_bits + (size_t)j * (size_t)(2 * W);
+  double p = d.prob[sl];
+  int n = 0;
+  for (int w = 0; w < W; ++w) {
+    unsigned long long touched = bits[w];
+    const unsigned long long hits = bits[W + w];
+    bits[w] = 0ull;
+    bits[W + w] = 0ull;
+    while (touched != 0ull) {
+      const unsigned long long lowest = touched & (0ull - touched);
+      p = vox_bayes(p, (hits & lowest) ? like_hit : like_miss);
+      ++n;
+      touched ^= lowest;
     }
-    for (int i = tid; i < len; i += nthr) {
-      if (i != tid) sl = slots[i];
-      if (sl == kVoxEmpty) continue;
-      const bool endpoint = (i == len - 1) && has_hit;                    // :121-123
-      d.prob[sl] = vox_bayes(d.prob[sl], endpoint ? like_hit : like_miss);
-      d.count[sl] += 1;
-      ++updates;
-    }
-    __syncthreads();
   }
-  if (stats != nullptr && updates) atomicAdd(&stats[0], updates);
+  d.prob[sl] = p;
+  d.count[sl] += n;
+  slot_rows[sl] = 0;
 }
 
 // ------------------------------------------------------------------------------------------ host side
@@ -537,31 +557,37 @@ extern "C" int se3mpc_voxel_export(const se3mpc_voxel_map* m, int32_t* ijk_out, 
 
 extern "C" int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
                                         const double* distance, const int32_t* hit, int M, double like_hit, double like_miss,
-                                        uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* stats, void* stream) {
+                                        uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* slot_rows,
+                                        uint64_t* row_bits, int32_t* stats, void* stream) {
   VoxDev d;
   int rc = make_vox_dev(m, d);
   if (rc) return rc;
-  if (M < 0 || max_len < 1 || (long long)M * max_len > (1ll << 31)) return SE3MPC_ERR_SHAPE;
+  if (M < 0 || M > SE3MPC_VOXEL_MAX_RAYS || max_len < 1 || (long long)M * max_len >= (1ll << 31)) return SE3MPC_ERR_SHAPE;
   if (!(like_hit > 0.0 && like_hit < 1.0 && like_miss > 0.0 && like_miss < 1.0)) return SE3MPC_ERR_PARAM;
   hipStream_t s = (hipStream_t)stream;
   if (stats != nullptr && hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), s) != hipSuccess)
     return launch_status("se3mpc_voxel_update_rays(memset)");
   if (M == 0) return SE3MPC_OK;
-  if (!origin || !direction || !distance || !hit || !ray_keys || !ray_len) return SE3MPC_ERR_NULL;
+  if (!origin || !direction || !distance || !hit || !ray_keys || !ray_len || !slot_rows || !row_bits) return SE3MPC_ERR_NULL;
+  const int W = (M + 63) / 64;
   hipLaunchKernelGGL(voxel_trace_kernel, dim3(grid_for(M, 64)), dim3(64), 0, s, d, origin, direction, distance, M,
                      reinterpret_cast<unsigned long long*>(ray_keys), ray_len, max_len, stats);
   rc = launch_status("se3mpc_voxel_update_rays(trace)");
   if (rc) return rc;
   const long long recs = (long long)M * max_len;
-  hipLaunchKernelGGL(voxel_resolve_kernel, dim3((unsigned)((recs + 255) / 256)), dim3(256), 0, s, d,
-                     reinterpret_cast<unsigned long long*>(ray_keys), ray_len, M, max_len, stats);
+  const unsigned nblk = (unsigned)((recs + 255) / 256);
+  hipLaunchKernelGGL(voxel_resolve_kernel, dim3(nblk), dim3(256), 0, s, d, reinterpret_cast<unsigned long long*>(ray_keys),
+                     ray_len, hit, M, max_len, slot_rows, reinterpret_cast<unsigned long long*>(row_bits), W, stats);
   rc = launch_status("se3mpc_voxel_update_rays(resolve)");
   if (rc) return rc;
-  int threads = 64;                                     // one lane per voxel of the longest possible ray, up to 1024
-  while (threads < max_len && threads < 1024) threads *= 2;
-  hipLaunchKernelGGL(voxel_apply_kernel, dim3(1), dim3(threads), 0, s, d, reinterpret_cast<const unsigned long long*>(ray_keys),
-                     ray_len, hit, M, max_len, like_hit, like_miss, stats);
+  hipLaunchKernelGGL(voxel_apply_kernel, dim3(nblk), dim3(256), 0, s, d, reinterpret_cast<const unsigned long long*>(ray_keys),
+                     ray_len, M, max_len, slot_rows, reinterpret_cast<unsigned long long*>(row_bits), W, like_hit, like_miss);
   return launch_status("se3mpc_voxel_update_rays(apply)");
+}
+
+extern "C" long long se3mpc_voxel_update_row_words(int M, int max_len) {
+  if (M < 1 || max_len < 1) return 0;
+  return (long long)M * max_len * 2 * ((M + 63) / 64);
 }
 
 extern "C" int se3mpc_voxel_local_workspace(int cells_per_axis) {

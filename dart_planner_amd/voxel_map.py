@@ -41,6 +41,8 @@ class DeviceVoxelMap:
         self.prob = self.be.empty((capacity,), "f64")
         self.count = self.be.empty((capacity,), "i32")
         self._scratch = self.be.empty((8,), "i32")
+        self._slot_rows = self._zeros((capacity,), "i32")       # update_rays workspace: zero between calls
+        self._row_bits = None
         self.desc = VoxelMapDesc(keys=self.be.ptr(self.keys), prob=self.be.ptr(self.prob), count=self.be.ptr(self.count),
                                  capacity=capacity, reserved=0, resolution=self.resolution, prior=self.prior)
 
@@ -98,11 +100,19 @@ class DeviceVoxelMap:
             self._n += int(f[1])
 
     def _zero_scratch(self) -> None:
-        z = self._scratch
+        self._fill_zero(self._scratch)
+
+    @staticmethod
+    def _fill_zero(z) -> None:
         if hasattr(z, "zero_"):
             z.zero_()
         else:
             z[...] = 0
+
+    def _zeros(self, shape, kind):
+        z = self.be.empty(shape, kind)
+        self._fill_zero(z)
+        return z
 
     def insert(self, ijk, prob=None, value: Optional[float] = None, counts=None) -> None:
         """Create-or-overwrite voxels by index: per-voxel `prob` or one `value` (what add_obstacle does with 0.9)."""
@@ -164,7 +174,8 @@ class DeviceVoxelMap:
 
     # ------------------------------------------------------------------ update_map
     def update_rays(self, origins, unit_directions, distances, hits, like_hit: float = 0.7, like_miss: float = 0.6):
-        """update_map (mapper.py:102-153) for M observations in order.  Returns (voxel updates, total voxels)."""
+        """update_map (mapper.py:102-153) for M observations in order (chunks of at most 1024 rays per launch group).
+        Returns (voxel updates, total voxels)."""
         o = np.ascontiguousarray(np.asarray(origins, np.float64).reshape(-1, 3))
         d = np.ascontiguousarray(np.asarray(unit_directions, np.float64).reshape(-1, 3))
         dist = np.ascontiguousarray(np.asarray(distances, np.float64).reshape(-1))
@@ -176,16 +187,26 @@ class DeviceVoxelMap:
             return 0, len(self)
         max_len = 3 * int(np.ceil(float(np.max(dist)) / self.resolution)) + 8
         self.reserve(int(np.sum(3 * np.ceil(dist / self.resolution) + 8)))       # every walked voxel could be new
-        ray_keys = self.be.empty((M, max_len), "i64")
-        ray_len = self.be.empty((M,), "i32")
+        chunk = min(M, 1024)
+        while chunk > 64 and self.lib.voxel_update_row_words(chunk, max_len) * 8 > (256 << 20):
+            chunk //= 2                                                            # keep the bit-set workspace under 256 MiB
+        words = self.lib.voxel_update_row_words(chunk, max_len)
+        if self._row_bits is None or int(np.prod(self._row_bits.shape)) < words:
+            self._row_bits = self._zeros((words,), "i64")
+        ray_keys = self.be.empty((chunk, max_len), "i64")
+        ray_len = self.be.empty((chunk,), "i32")
         stats = self.be.empty((4,), "i32")
-        d_o, d_d, d_dist, d_hit = (self.be.from_host(x) for x in (o, d, dist, hit))
-        self.lib.voxel("update_rays", self.desc, self.be.ptr(d_o), self.be.ptr(d_d), self.be.ptr(d_dist), self.be.ptr(d_hit), M,
-                       float(like_hit), float(like_miss), self.be.ptr(ray_keys), self.be.ptr(ray_len), max_len,
-                       self.be.ptr(stats), self.be.stream())
-        st = self.be.to_host(stats)
-        if int(st[1]) or int(st[2]):
-            raise RuntimeError(f"voxel update dropped work: {int(st[1])} voxels not stored, {int(st[2])} rays truncated")
-        if self._n is not None:
-            self._n += int(st[3])
-        return int(st[0]), len(self)
+        updates = 0
+        for lo in range(0, M, chunk):
+            hi = min(M, lo + chunk)
+            d_o, d_d, d_dist, d_hit = (self.be.from_host(x[lo:hi]) for x in (o, d, dist, hit))
+            self.lib.voxel("update_rays", self.desc, self.be.ptr(d_o), self.be.ptr(d_d), self.be.ptr(d_dist), self.be.ptr(d_hit),
+                           hi - lo, float(like_hit), float(like_miss), self.be.ptr(ray_keys), self.be.ptr(ray_len), max_len,
+                           self.be.ptr(self._slot_rows), self.be.ptr(self._row_bits), self.be.ptr(stats), self.be.stream())
+            st = self.be.to_host(stats)
+            if int(st[1]) or int(st[2]):
+                raise RuntimeError(f"voxel update dropped work: {int(st[1])} voxels not stored, {int(st[2])} rays truncated")
+            updates += int(st[0])
+            if self._n is not None:
+                self._n += int(st[3])
+        return updates, len(self)

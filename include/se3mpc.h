@@ -273,17 +273,24 @@ int se3mpc_voxel_clear(const se3mpc_voxel_map* m, void* stream);
  * out of range), [1] per voxel that did not exist before. */
 int se3mpc_voxel_insert(const se3mpc_voxel_map* m, const int32_t* ijk, const double* prob, double value,
                         const int32_t* count_in, int M, int32_t* failed, void* stream);
-/* update_map (mapper.py:102-153) for M observations in their order: origin [M][3], direction [M][3] (UNIT vectors:
- * the caller normalises, as mapper.py:265 does), distance [M] = min(hit_distance or max_range, map max_range)
- * (:111-112), hit [M] = 1 when the observation carries a hit distance (the ray's last voxel is then updated with
- * like_hit = prob_hit, every other voxel with like_miss = 1 - prob_miss, :319-323).  Voxels are walked with the
- * reference's DDA (:251-312) and updated ray after ray, because the clamped Bayesian update (:325-337) does not
- * commute.  Workspace: ray_keys device uint64 [M][max_len], ray_len device int32 [M]; max_len >=
- * 3 * ceil(distance / resolution) + 8 never truncates.  stats: device int32[4] = {voxel updates, voxels that
- * could not be stored, truncated rays, voxels created} (reset by the call). */
+/* update_map (mapper.py:102-153) for M <= SE3MPC_VOXEL_MAX_RAYS observations in their order (longer scans: call
+ * again with the next chunk): origin [M][3], direction [M][3] (UNIT vectors: the caller normalises, as
+ * mapper.py:265 does), distance [M] = min(hit_distance or max_range, map max_range) (:111-112), hit [M] = 1 when the
+ * observation carries a hit distance (the ray's last voxel is then updated with like_hit = prob_hit, every other
+ * voxel with like_miss = 1 - prob_miss, :319-323).  Voxels are walked with the reference's DDA (:251-312); the
+ * clamped Bayesian update (:325-337) does not commute, so every voxel applies its observations in ray order (voxels
+ * are independent of each other and proceed in parallel).
+ * Workspace (device): ray_keys uint64 [M][max_len] and ray_len int32 [M] (max_len >= 3 * ceil(distance /
+ * resolution) + 8 never truncates); slot_rows int32 [capacity] and row_bits uint64
+ * [se3mpc_voxel_update_row_words(M, max_len)], both ALL ZERO on entry and left all zero on return.
+ * stats: device int32[4] = {voxels walked, walked voxels that could not be stored, truncated rays, voxels created}
+ * (reset by the call). */
+#define SE3MPC_VOXEL_MAX_RAYS 1024
 int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
                              const double* distance, const int32_t* hit, int M, double like_hit, double like_miss,
-                             uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* stats, void* stream);
+                             uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* slot_rows, uint64_t* row_bits,
+                             int32_t* stats, void* stream);
+long long se3mpc_voxel_update_row_words(int M, int max_len);
 /* Compact the occupied slots (order unspecified): ijk_out [capacity][3], prob_out / count_out [capacity] (may be
  * NULL), *n_out = number of voxels (the caller zeroes nothing: the function resets *n_out itself). */
 int se3mpc_voxel_export(const se3mpc_voxel_map* m, int32_t* ijk_out, double* prob_out, int32_t* count_out,

@@ -175,4 +175,6 @@ inline unsigned long long atomicCAS(unsigned long long* p, unsigned long long ex
   return old;
 }
 inline int atomicAdd(int* p, int v) { int old = *p; *p = old + v; return old; }
+inline int atomicCAS(int* p, int expect, int desired) { int old = *p; if (old == expect) *p = desired; return old; }
+inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { unsigned long long old = *p; *p = old | v; return old; }
 inline void __threadfence() {}
