@@ -118,6 +118,7 @@ _TYPED_API = {
     "argmin": (False, [_I, _P, C.c_uint32, _P, _P]),
     "spheres_from_grid": (False, [_P, _P, _I, C.c_double, _I, C.c_double, _P, _I, _P, _P]),
     "transpose": (False, [_I, _I, _P, _I, _P, _I, _P]),
+    "population_sums": (False, [_I, _I, _I, _P, _P, _D, _P, _D, _P, _P, _P]),
     "solve": (True, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
 }
 # voxel map: se3mpc_voxel_<base>_<suffix>(const se3mpc_voxel_map*, ...)
@@ -144,6 +145,7 @@ _PLAIN_API = {
     "se3mpc_reduce_keys": (C.c_int, [_P, _I, _I, _P, _P]),
     "se3mpc_key_index": (C.c_uint32, [C.c_uint64]),
     "se3mpc_key_cost": (C.c_float, [C.c_uint64]),
+    "se3mpc_population_workspace": (C.c_int, [_I, _I]),
 }
 
 
@@ -218,6 +220,9 @@ class Library:
 
     def reduce_keys(self, wave_keys: int, per_batch: int, nbatch: int, keys_out: int, stream: int) -> None:
         self._check("se3mpc_reduce_keys", self._dll.se3mpc_reduce_keys(wave_keys, per_batch, nbatch, keys_out, stream))
+
+    def population_workspace(self, rows: int, B: int) -> int:
+        return self._dll.se3mpc_population_workspace(rows, B)
 
     def key_index(self, key: int) -> int:
         return self._dll.se3mpc_key_index(C.c_uint64(key))

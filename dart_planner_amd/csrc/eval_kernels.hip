@@ -791,6 +791,45 @@ argmin_kernel(int B, const R* __restrict__ cost, uint32_t index_base, unsigned l
   }
 }
 
+// Population sums of a lane-layout block: part[split][r] = sum over the split's trajectories of w_b * X[r][b]
+// (r < rows) and part[split][rows] = sum of w_b, in float64.  w_b = 1, or the MPPI weight
+// exp(-(cost_b - cost_ref) / temperature).  One workgroup per (row, split); a fixed summation tree (lane-strided
+// partials, DPP wave sum, four wave totals in order), so the result does not depend on scheduling.
+template <typename R>
+__global__ void __launch_bounds__(256)
+population_sums_kernel(int rows, int B, int ld, const R* __restrict__ X, const R* __restrict__ cost, double cost_ref,
+                       const unsigned long long* __restrict__ ref_key, double inv_temperature, int per_split,
+                       double* __restrict__ part) {
+  __shared__ double wave_tot[4];
+  const int r = blockIdx.x, split = blockIdx.y;
+  const int lo = split * per_split, hi = (lo + per_split < B) ? lo + per_split : B;
+  if (ref_key != nullptr) {
+    uint32_t u = (uint32_t)(ref_key[0] >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u;               // se3mpc_key_cost
+    cost_ref = (double)__uint_as_float(u);
+  }
+  const R* row = r < rows ? X + (size_t)r * ld : nullptr;
+  double acc = 0.0;
+  for (int b = lo + threadIdx.x; b < hi; b += blockDim.x) {
+    const double w = cost != nullptr ? exp(-((double)cost[b] - cost_ref) * inv_temperature) : 1.0;
+    acc += row != nullptr ? w * (double)row[b] : w;
+  }
+  acc = wave_sum(acc);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) wave_tot[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)split * (rows + 1) + r] = ((wave_tot[0] + wave_tot[1]) + wave_tot[2]) + wave_tot[3];
+}
+
+__global__ void __launch_bounds__(256)
+population_fold_kernel(int n, int nsplit, const double* __restrict__ part, double* __restrict__ out) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  double acc = 0.0;
+  for (int sp = 0; sp < nsplit; ++sp) acc += part[(size_t)sp * n + r];
+  out[r] = acc;
+}
+
 // keys_out[batch] = min over the batch's wave-key slots (one workgroup per batch, plain store)
 __global__ void __launch_bounds__(256)
 reduce_keys_kernel(const unsigned long long* __restrict__ wave_keys, int per_batch, unsigned long long* __restrict__ keys_out) {
@@ -1122,6 +1161,34 @@ int argmin_impl(int B, const R* cost, uint32_t index_base, uint64_t* key, void* 
   return launch_status("se3mpc_argmin");
 }
 
+static int population_splits(int B) {
+  int n = B / 65536;
+  return n < 1 ? 1 : (n > 16 ? 16 : n);
+}
+
+template <typename R>
+int population_sums_impl(int rows, int B, int ld, const R* X, const R* cost, double cost_ref, const uint64_t* ref_key,
+                         double temperature, double* out, double* workspace, void* stream) {
+  if (rows < 0 || B < 0 || ld < B) return SE3MPC_ERR_SHAPE;
+  if (!out) return SE3MPC_ERR_NULL;
+  if (cost != nullptr && (!(temperature > 0.0) || !std::isfinite(temperature) || !std::isfinite(cost_ref))) return SE3MPC_ERR_PARAM;
+  hipStream_t s = (hipStream_t)stream;
+  if (B == 0) {
+    if (hipMemsetAsync(out, 0, (size_t)(rows + 1) * sizeof(double), s) != hipSuccess) return launch_status("se3mpc_population_sums(memset)");
+    return SE3MPC_OK;
+  }
+  if ((rows > 0 && !X) || !workspace) return SE3MPC_ERR_NULL;
+  const int nsplit = population_splits(B);
+  const int per_split = (B + nsplit - 1) / nsplit;
+  hipLaunchKernelGGL(population_sums_kernel<R>, dim3(rows + 1, nsplit), dim3(256), 0, s, rows, B, ld, X, cost, cost_ref,
+                     reinterpret_cast<const unsigned long long*>(ref_key), cost != nullptr ? 1.0 / temperature : 0.0, per_split,
+                     workspace);
+  int rc = launch_status("se3mpc_population_sums");
+  if (rc) return rc;
+  hipLaunchKernelGGL(population_fold_kernel, dim3(grid_for(rows + 1, 256)), dim3(256), 0, s, rows + 1, nsplit, workspace, out);
+  return launch_status("se3mpc_population_sums(fold)");
+}
+
 template <typename R>
 int spheres_from_grid_impl(const R* pos, const R* occ, int M, double threshold, int target, double radius, R* spheres, int cap,
                            int32_t* count, void* stream) {
@@ -1225,3 +1292,15 @@ extern "C" int se3mpc_set_rollout_variant(int variant) {
 
 SE3MPC_DEFINE_LANE_API(f32, float)
 SE3MPC_DEFINE_LANE_API(f64, double)
+
+extern "C" int se3mpc_population_workspace(int rows, int B) { return B < 1 ? 1 : (rows + 1) * population_splits(B); }
+extern "C" int se3mpc_population_sums_f32(int rows, int B, int ld, const float* X, const float* cost, double cost_ref,
+                                          const uint64_t* ref_key, double temperature, double* out, double* workspace,
+                                          void* stream) {
+  return population_sums_impl<float>(rows, B, ld, X, cost, cost_ref, ref_key, temperature, out, workspace, stream);
+}
+extern "C" int se3mpc_population_sums_f64(int rows, int B, int ld, const double* X, const double* cost, double cost_ref,
+                                          const uint64_t* ref_key, double temperature, double* out, double* workspace,
+                                          void* stream) {
+  return population_sums_impl<double>(rows, B, ld, X, cost, cost_ref, ref_key, temperature, out, workspace, stream);
+}

@@ -66,6 +66,20 @@ def allreduce_min_keys(keys):
     return keys
 
 
+def allreduce_population_mean(sums):
+    """The population mean over all ranks from per-rank `Ops.population_sums` outputs (rows + 1 float64 values, the
+    last one the weight total): ONE all-reduce(SUM), then the division.  -> tensor (rows,) on the sums' device."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "gloo" and sums.is_cuda:
+            h = sums.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            sums.copy_(h)
+        else:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums[:-1] / sums[-1]
+
+
 def key_index(key: int) -> int:
     return int(key) & 0xFFFFFFFF
 

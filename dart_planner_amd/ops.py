@@ -284,6 +284,24 @@ class Ops:
         k = int(self.be.to_host(key).reshape(-1)[0]) & 0xFFFFFFFFFFFFFFFF
         return self.lib.key_index(k), self.lib.key_cost(k)
 
+    def population_sums(self, X, cost=None, temperature: float = 1.0, cost_ref: float = 0.0, ref_key=None, B: Optional[int] = None):
+        """out[r] = sum_b w_b X[r][b] (r < rows), out[rows] = sum_b w_b in float64; w = 1, or the MPPI weight
+        exp(-(cost - cost_ref) / temperature) with cost_ref taken from the packed argmin key `ref_key` (device) when
+        given.  X: (rows, ld) lane layout.  -> device float64 (rows + 1,)."""
+        self.be.check(X, "X")
+        if X.ndim != 2:
+            raise ValueError("X: expected (rows, ld)")
+        rows, ld = X.shape
+        B = self._B(ld, B)
+        suf = self.be.suffix(X)
+        if cost is not None and (self.be.suffix(self.be.check(cost, "cost")) != suf or cost.shape[-1] < B):
+            raise ValueError("cost: same dtype as X and at least B entries")
+        out = self.be.empty((rows + 1,), "f64")
+        work = self.be.empty((self.lib.population_workspace(rows, B),), "f64")
+        self.lib.call("population_sums", suf, rows, B, ld, self.be.ptr(X), self.be.ptr(cost), float(cost_ref), self.be.ptr(ref_key),
+                      float(temperature), self.be.ptr(out), self.be.ptr(work), self.be.stream())
+        return out
+
     def spheres_from_grid(self, positions, occupancy, threshold: float = 0.6, target: int = 20, radius: float = 1.0,
                           cap: int = 64):
         """Occupancy grid -> sphere table on the device (f-2).  positions (M, 3), occupancy (M,) in the

@@ -229,6 +229,20 @@ int se3mpc_argmin_f64(int B, const double* cost, uint32_t index_base, uint64_t* 
 uint32_t se3mpc_key_index(uint64_t key);
 float se3mpc_key_cost(uint64_t key);   /* f64 costs are ordered through their float rounding */
 
+/* Population sums of a lane-layout block -- the other exchange of the multi-GPU path ("for an
+ * MPPI-style averaged gradient: all-reduce(SUM) of 3N floats"): out[r] = sum_b w_b * X[r][b] for r < rows and
+ * out[rows] = sum_b w_b, accumulated in float64 with a fixed summation tree.  w_b = 1 when cost == NULL (plain
+ * mean of, e.g., the rollout's thrust gradient), else the MPPI weight exp(-(cost[b] - cost_ref) / temperature),
+ * where cost_ref is the host argument, or -- when ref_key != NULL -- the cost held in that device key (the fused /
+ * all-reduced argmin key: the global minimum, so every rank weighs on the same scale).  One all-reduce(SUM) of the
+ * rows + 1 doubles, then out[r] / out[rows], gives the population mean over all ranks.
+ * workspace: device double[se3mpc_population_workspace(rows, B)]. */
+int se3mpc_population_workspace(int rows, int B);
+int se3mpc_population_sums_f32(int rows, int B, int ld, const float* X, const float* cost, double cost_ref,
+                               const uint64_t* ref_key, double temperature, double* out, double* workspace, void* stream);
+int se3mpc_population_sums_f64(int rows, int B, int ld, const double* X, const double* cost, double cost_ref,
+                               const uint64_t* ref_key, double temperature, double* out, double* workspace, void* stream);
+
 /* Obstacle source: the sphere table of se3mpc_obstacle_residual_* straight from a local
  * occupancy grid, replacing the host loop of cloud/main_improved_threelayer.py:387-398 (target 20) and
  * tests/test_se3_mpc_with_mapper.py:29-33 (target 10): occupied = cells with occupancy > threshold in grid

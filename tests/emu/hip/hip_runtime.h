@@ -148,6 +148,7 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 
 inline void __syncthreads() { ::emu::sync(); }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 
 template <typename T>
 inline T __shfl_down(T v, int off, int width = 64) {

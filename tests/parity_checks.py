@@ -331,3 +331,28 @@ def check_solver_edge_inputs(h: Harness):
     finite_goal = np.isfinite(G).all(axis=1)
     assert np.all(np.isfinite(h.to_host(out["x"])[finite_goal]))
     assert np.all(info["status"][~finite_goal] == 2)
+
+
+def check_population_sums(h: Harness, rows=90, B=1000, seed=0):
+    """se3mpc_population_sums_* against float64 NumPy on the same (rounded) inputs: plain sums, MPPI weights with a
+    host reference cost and with the reference taken from a device argmin key; ld > B; B = 0."""
+    rng = np.random.default_rng(seed)
+    ld = B + 7
+    X = rng.normal(size=(rows, ld)).astype(h.dt)
+    cost = rng.uniform(50.0, 80.0, ld).astype(h.dt)
+    dX, dc = h.to_dev(X), h.to_dev(cost)
+    Xd, cd = X[:, :B].astype(np.float64), cost[:B].astype(np.float64)
+    out = h.to_host(h.ops.population_sums(dX, B=B))
+    assert np.allclose(out[:rows], Xd.sum(1), rtol=1e-12, atol=1e-9) and out[rows] == B
+    lam, ref = 2.5, float(cd.min())
+    w = np.exp(-(cd - ref) / lam)
+    out = h.to_host(h.ops.population_sums(dX, cost=dc, temperature=lam, cost_ref=ref, B=B))
+    assert np.allclose(out[:rows], (Xd * w).sum(1), rtol=1e-11, atol=1e-9) and np.isclose(out[rows], w.sum(), rtol=1e-12)
+    key = h.to_dev(np.zeros(1, dtype=np.int64))
+    h.ops.argmin(h.to_dev(np.ascontiguousarray(cost[:B])), index_base=0, out=key)
+    ref32 = float(np.float32(cd.min()))                            # the key carries the cost as float32
+    w = np.exp(-(cd - ref32) / lam)
+    out = h.to_host(h.ops.population_sums(dX, cost=dc, temperature=lam, ref_key=key, B=B))
+    assert np.allclose(out[:rows], (Xd * w).sum(1), rtol=1e-11, atol=1e-9) and np.isclose(out[rows], w.sum(), rtol=1e-12)
+    out = h.to_host(h.ops.population_sums(dX, B=0))
+    assert np.all(out == 0)

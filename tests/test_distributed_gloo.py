@@ -36,8 +36,25 @@ def _worker(rank, world, port, q):
     raw = [((0x80000000 | (100 + 7 * rank)) << 32) | (10 * rank + 1), ((0x80000000 | (50 - rank)) << 32) | (10 * rank + 2)]
     keys = torch.from_numpy(np.array(raw, dtype=np.uint64).view(np.int64).copy())
     D.allreduce_min_keys(keys)
-    q.put((rank, res["restart"], res["owner"], res["cost"], res["x"], keys.numpy().view(np.uint64).tolist()))
+    # population mean (MPPI weights on the GLOBAL minimum: the all-reduced key) over a batch sharded across the ranks
+    ops = _ops()
+    Xall, call = _population()
+    lo, hi = D.shard_bounds(Xall.shape[1], rank, world)
+    Xs, cs = torch.from_numpy(np.ascontiguousarray(Xall[:, lo:hi])), torch.from_numpy(np.ascontiguousarray(call[lo:hi]))
+    kmin = torch.zeros(1, dtype=torch.int64)
+    ops.argmin(cs, index_base=lo, out=kmin)
+    D.allreduce_min_keys(kmin)
+    mean = D.allreduce_population_mean(ops.population_sums(Xs, cost=cs, temperature=POP_TEMPERATURE, ref_key=kmin))
+    q.put((rank, res["restart"], res["owner"], res["cost"], res["x"], keys.numpy().view(np.uint64).tolist(), mean.numpy()))
     torch.distributed.destroy_process_group()
+
+
+POP_TEMPERATURE = 3.0
+
+
+def _population():
+    rng = np.random.default_rng(9)
+    return rng.normal(size=(18, 301)).astype(np.float32), rng.uniform(100.0, 130.0, 301).astype(np.float32)
 
 
 def test_shard_bounds():
@@ -65,7 +82,11 @@ def test_two_rank_restart_argmin_matches_single_process():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, restart, owner, cost, x, keys in got:
+    Xall, call = _population()
+    w = np.exp(-(call.astype(np.float64) - float(call.min())) / POP_TEMPERATURE)
+    mean_ref = (Xall.astype(np.float64) * w).sum(1) / w.sum()
+    for rank, restart, owner, cost, x, keys, mean in got:
+        assert np.allclose(mean, mean_ref, rtol=1e-12, atol=1e-14)
         assert restart == single["restart"] and cost == single["cost"]
         assert np.array_equal(x, single["x"])
         assert owner == (0 if restart < 3 else 1)                      # shards: rank 0 -> [0,3), rank 1 -> [3,5)

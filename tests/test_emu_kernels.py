@@ -71,6 +71,11 @@ def test_solver_edge_inputs(emu_ops, dt):
     pc.check_solver_edge_inputs(harness(emu_ops, dt))
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_population_sums(emu_ops, dt):
+    pc.check_population_sums(harness(emu_ops, dt), rows=18, B=333)
+
+
 def test_empty_batch_and_error_codes(emu_ops):
     lib, be = emu_ops.lib, emu_ops.be
     prm = capi.Params.reference_defaults(horizon=6)

@@ -36,6 +36,12 @@ def test_lane_kernels(gpu_ops, dt, N, B):
     pc.check_lane_kernels(harness(gpu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5, 6))
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("rows,B", [(90, 8192), (150, 200001), (3, 64)])
+def test_population_sums(gpu_ops, dt, rows, B):
+    pc.check_population_sums(harness(gpu_ops, dt), rows=rows, B=B, seed=rows)
+
+
 def test_lane_kernels_other_dt(gpu_ops):
     pc.check_lane_kernels(harness(gpu_ops, np.float64), 20, 300, seed=2, dt=0.05)
     pc.check_lane_kernels(harness(gpu_ops, np.float32), 20, 300, seed=2, dt=0.1)
