@@ -259,10 +259,15 @@ class SE3MPCPlanner(BasePlanner):
         return self._solve_batch(p0, v0, g, x0, precision or "f32")
 
     def plan_with_restarts(self, current_state: DroneState, goal_position, n_restarts: int = 256, sigma: float = 1.0,
-                           seed: int = 0, precision: Optional[str] = None) -> Trajectory:
+                           seed: int = 0, precision: Optional[str] = None, mapper=None, safety_margin: float = 1.0,
+                           occupancy_threshold: float = 0.6) -> Trajectory:
         """R cold starts of ONE problem: restart 0 is the reference's straight-line start, restarts
         1..R-1 add N(0, sigma) newtons to its thrust block (the solver projects into the box);
-        the restart with the lowest final objective wins."""
+        the restart with the lowest final objective wins.  With a `mapper` (the device
+        ExplicitGeometricMapper) the winner is taken among the restarts whose positions pass its
+        is_trajectory_safe check (mapper.py:195-219, all R plans in one launch) -- what
+        cloud/main_improved_se3.py:128 does to a single plan after the fact; if none passes, the lowest
+        objective wins as before and ``last_result["n_safe"]`` is 0."""
         current_state, _, _ = self.sense(current_state, goal_position)
         N, R = self.se3_config.prediction_horizon, int(n_restarts)
         p0 = np.tile(np.asarray(to_float(current_state.position), float), (R, 1))
@@ -272,9 +277,15 @@ class SE3MPCPlanner(BasePlanner):
         rng = np.random.default_rng(seed)
         x0[1:, 6 * N:] += rng.normal(0.0, sigma, (R - 1, 3 * N))
         res = self._solve_batch(p0, v0, g, x0, precision or self.precision)
-        best = int(np.argmin(res["info"]["fun"]))
-        self.last_result = dict(best_restart=best, fun=float(res["info"]["fun"][best]),
-                                fun_cold_start=float(res["info"]["fun"][0]))
+        fun = np.array(res["info"]["fun"], dtype=float)
+        self.last_result = dict(fun_cold_start=float(fun[0]))
+        if mapper is not None:
+            safe, _ = mapper.trajectories_safe(res["positions"], safety_margin, occupancy_threshold)
+            self.last_result["n_safe"] = int(safe.sum())
+            if safe.any():
+                fun = np.where(safe, fun, np.inf)
+        best = int(np.argmin(fun))
+        self.last_result.update(best_restart=best, fun=float(res["info"]["fun"][best]))
         sol = {k: res[k][best] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes",
                                          "body_rates", "thrusts")}
         return self._create_trajectory_from_solution(sol, time.time())

@@ -52,3 +52,4 @@ def test_mapper_feeds_planner(emu_ops):
         pl._ops = tops
         return pl
     vc.check_mapper_planner_loop(tops, factory, steps=2)
+    vc.check_restarts_filtered_by_map(tops, factory, n_restarts=12)

@@ -47,6 +47,7 @@ def test_edges_and_statuses(gpu_ops):
 def test_mapper_feeds_planner(gpu_ops):
     from dart_planner_amd.planning.se3_mpc_planner import SE3MPCPlanner
     vc.check_mapper_planner_loop(gpu_ops, lambda: SE3MPCPlanner(), steps=5)
+    vc.check_restarts_filtered_by_map(gpu_ops, lambda: SE3MPCPlanner(precision="f64"), n_restarts=256)
 
 
 def test_update_is_order_exact_under_repetition(gpu_ops, golden_map):

@@ -152,3 +152,30 @@ def check_mapper_planner_loop(ops, planner_factory, steps=3):
         state.position = state.position + 0.3 * (traj.positions[1] - state.position)
         state.timestamp += planner.se3_config.dt
     return mapper
+
+
+def check_restarts_filtered_by_map(ops, planner_factory, n_restarts=48):
+    """plan_with_restarts(mapper=...): the winner is the lowest-objective restart among those the map calls safe."""
+    from dart_planner_amd.common.types import DroneState
+    planner = planner_factory()
+    mapper = ExplicitGeometricMapper(resolution=0.5, max_range=40.0, ops=ops)
+    state = DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 2.0]), velocity=np.zeros(3), attitude=np.zeros(3),
+                       angular_velocity=np.zeros(3))
+    goal = np.array([6.0, 0.5, 2.5])
+    free = planner.plan_with_restarts(state, goal, n_restarts=n_restarts, sigma=2.0, seed=1, mapper=mapper)
+    assert planner.last_result["n_safe"] == n_restarts                       # empty map: everything is safe
+    unfiltered = planner.plan_with_restarts(state, goal, n_restarts=n_restarts, sigma=2.0, seed=1)
+    assert np.array_equal(free.positions, unfiltered.positions)
+    # occupied voxels over the first planned position (the reference's objective decouples the position block from the
+    # thrust block, so every restart plans the same positions): nothing passes, the lowest objective still comes back
+    mapper.add_obstacle(np.array(unfiltered.positions[0], float), 1.5)
+    blocked = planner.plan_with_restarts(state, goal, n_restarts=n_restarts, sigma=2.0, seed=1, mapper=mapper)
+    assert planner.last_result["n_safe"] == 0 and np.array_equal(blocked.positions, unfiltered.positions)
+    # the selection rule itself, against the per-restart answers of the reference-shaped call
+    m2 = ExplicitGeometricMapper(resolution=0.5, max_range=40.0, ops=ops)
+    m2.add_obstacle(unfiltered.positions[-1] + np.array([0.0, 0.0, 0.9]), 0.5)     # clips the unfiltered winner's last step
+    res = planner.plan_batch(np.tile(state.position, (3, 1)), np.zeros((3, 3)), np.tile(goal, (3, 1)), precision="f64")
+    for P in res["positions"]:
+        ok, first = m2.is_trajectory_safe(P, 1.0, 0.6)
+        s_b, f_b = m2.trajectories_safe(P[None], 1.0, 0.6)
+        assert (ok, first) == (bool(s_b[0]), int(f_b[0]))
