@@ -7,9 +7,9 @@ class NumpyBackend:
     _dt = {"f32": np.float32, "f64": np.float64, "i32": np.int32, "i64": np.int64, "u8": np.uint8}
 
     def empty(self, shape, kind):
-        return np.full(shape, 0x7B, dtype=np.uint8).view(np.uint8)[:0].copy() if False else \
-            np.frombuffer(bytearray(b"\x7b" * (int(np.prod(shape)) * np.dtype(self._dt[kind]).itemsize)),
-                          dtype=self._dt[kind]).reshape(shape)
+        """Like torch.empty, but poisoned: every byte is 0x7B, so a kernel that forgets to write shows up."""
+        nbytes = int(np.prod(shape)) * np.dtype(self._dt[kind]).itemsize
+        return np.frombuffer(bytearray(b"\x7b" * nbytes), dtype=self._dt[kind]).reshape(shape)
 
     def suffix(self, a):
         if a.dtype == np.float32:
