@@ -935,7 +935,7 @@ constexpr int kLaneBlock = 64;   // one wavefront per workgroup: small batches s
 template <typename R>
 int init_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal, int project, R* X0,
               void* stream) {
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !X0 || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
@@ -946,7 +946,7 @@ int init_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, c
 
 template <typename R>
 int cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* goal, R* f, R* g, void* stream) {
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || !f || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
@@ -959,7 +959,7 @@ int cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* g
 template <typename R>
 int dynamics_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* p0, const R* v0, R* Rout,
                            void* stream) {
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || !p0 || !v0 || !Rout) return SE3MPC_ERR_NULL;
@@ -983,7 +983,7 @@ int obstacle_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, co
 
 template <typename R>
 int physical_constraints_impl(const se3mpc_params* p, int B, int ld, const R* X, R* C, void* stream) {
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || !C) return SE3MPC_ERR_NULL;
@@ -994,7 +994,7 @@ int physical_constraints_impl(const se3mpc_params* p, int B, int ld, const R* X,
 
 template <typename R>
 int extract_impl(const se3mpc_params* p, int B, int ld, const R* T, R* acc, R* att, R* rates, R* thrust, void* stream) {
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!T) return SE3MPC_ERR_NULL;
@@ -1081,12 +1081,11 @@ int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
                            void* stream) {
   unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
   if (nbatch < 1 || nbatch > 65535) return SE3MPC_ERR_SHAPE;
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));   // tallest operand: 3N rows (32-bit buffer offsets)
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !T || !cost || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
   if ((P == nullptr) != (V == nullptr)) return SE3MPC_ERR_NULL;   // states come as a pair
-  if ((uint64_t)3 * p->horizon * (uint64_t)ld * sizeof(R) >= (1ull << 32)) return SE3MPC_ERR_SHAPE;   // 32-bit buffer offsets
   hipStream_t s = (hipStream_t)stream;
   const int var = g_rollout_variant & 127;
   const bool grad = gradT != nullptr, states = P != nullptr;
@@ -1138,7 +1137,7 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
 
 template <typename R>
 int is_plan_valid_impl(const se3mpc_params* p, int B, int ld, const R* P, const R* V, int32_t* valid, void* stream) {
-  int rc = check_lane_args(p, B, ld);
+  int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!P || !valid) return SE3MPC_ERR_NULL;

@@ -99,6 +99,13 @@ def test_empty_batch_and_error_codes(emu_ops):
               0, 0, 0, params=prm) == -1                                                          # P without V
     with pytest.raises(capi.Se3mpcError):
         lib.call("cost_grad", "f32", 4, 4, 0, be.ptr(a), be.ptr(f), 0, 0, params=prm)
+    # size limits follow the tallest operand and the element size (32-bit buffer offsets): bench.py --sweep's
+    # 4 M-rollout batch is legal for the rollout (3N rows of f32), a full 9N-row f64 block of that width is not
+    p30 = capi.Params.reference_defaults(horizon=30)
+    assert st("rollout_cost_grad", "f32", 0, 1 << 22, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, params=p30) == 0
+    assert st("rollout_cost_grad", "f64", 0, 1 << 23, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, params=p30) == -3
+    assert st("cost_grad", "f32", 0, 1 << 21, 0, 0, 0, 0, 0, params=p30) == 0
+    assert st("cost_grad", "f64", 0, 1 << 21, 0, 0, 0, 0, 0, params=p30) == -3
 
 
 def test_defaults_and_key_codec(emu_ops):
