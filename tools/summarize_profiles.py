@@ -51,12 +51,15 @@ out = {"rollout_fused_64x8192_graph": durations(tr, 64), "rollout_single_8192_gr
        "solve_kernel_single_problem": None, "solve_kernel_batch_8192": None}
 sv = rows_of("solve", "solve_kernel")
 if sv:
-    # every solve is two back-to-back launches: tier 1 (LDS for 4 L-BFGS pairs, all problems) and tier 2 (full LDS,
-    # every wavefront but the overflowed ones exits at once): alternate dispatches of the same grid
-    for name, grid in (("single_problem", 64), ("batch_8192", 64 * B)):
-        grp = sorted((r for r in sv if int(r["Grid_Size_X"]) == grid), key=lambda r: int(r["Dispatch_Id"]))
-        out[f"solve_kernel_{name}_tier1"] = durations(grp[0::2])
-        out[f"solve_kernel_{name}_tier2_empty"] = durations(grp[1::2])
+    # up to 1024 problems a solve is ONE launch (full L-BFGS memory in LDS); larger batches are two back-to-back
+    # launches: tier 1 (LDS for 4 pairs, all problems) and tier 2 (full LDS, every wavefront but the overflowed ones
+    # exits at once) -- alternate dispatches of the same grid.  The single-problem group holds the f64 and the f32 legs.
+    single = sorted((r for r in sv if int(r["Grid_Size_X"]) == 64), key=lambda r: int(r["Dispatch_Id"]))
+    out["solve_kernel_single_problem_f64"] = durations([r for r in single if "<double" in r["Kernel_Name"]])
+    out["solve_kernel_single_problem_f32"] = durations([r for r in single if "<float" in r["Kernel_Name"]])
+    grp = sorted((r for r in sv if int(r["Grid_Size_X"]) == 64 * B), key=lambda r: int(r["Dispatch_Id"]))
+    out["solve_kernel_batch_8192_tier1"] = durations(grp[0::2])
+    out["solve_kernel_batch_8192_tier2_empty"] = durations(grp[1::2])
     del out["solve_kernel_single_problem"], out["solve_kernel_batch_8192"]
 for tag, rollouts, gy in (("fused", 64 * B, 64), ("single", B, None), ("b4m", 4194304, None)):
     alg_r = 4 * (3 * N + 9) * rollouts
