@@ -318,15 +318,16 @@ voxel_trace_kernel(VoxDev d, const double* __restrict__ origin, const double* __
   const double d0 = direction[3 * ray], d1 = direction[3 * ray + 1], d2 = direction[3 * ray + 2];
   const double f0 = floor(s0 / res), f1 = floor(s1 / res), f2 = floor(s2 / res);
   const double g0 = floor((s0 + d0 * dist) / res), g1 = floor((s1 + d1 * dist) / res), g2 = floor((s2 + d2 * dist) / res);   // :268-270
-  // both end voxels inside the packable range <=> every voxel of the walk is (it stays in their bounding box); a ray
-  // that leaves the range cannot be stored and is dropped as a whole (counted in stats[1])
-  const double lim = (double)(kVoxBias - 1);
+  // both end voxels well inside the packable range => every voxel of the walk is: it stays in their bounding box,
+  // except that rounding may carry it a step or two past the end voxel before `total > distance` stops it (hence the
+  // margin).  A ray that leaves the range cannot be stored and is dropped as a whole (counted in stats[1]).
+  const double lim = (double)(kVoxBias - 16);
   const bool ok = fabs(f0) <= lim && fabs(f1) <= lim && fabs(f2) <= lim && fabs(g0) <= lim && fabs(g1) <= lim && fabs(g2) <= lim;
   unsigned long long* out = ray_keys + (size_t)ray * (size_t)max_len;
   int len = 0;
   bool truncated = false;
   if (ok) {
-    int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
+    const int c0 = (int)f0, c1 = (int)f1, c2 = (int)f2;
     const int e0 = (int)g0, e1 = (int)g1, e2 = (int)g2;
     const int st0 = e0 > c0 ? 1 : (e0 < c0 ? -1 : 0), st1 = e1 > c1 ? 1 : (e1 < c1 ? -1 : 0), st2 = e2 > c2 ? 1 : (e2 < c2 ? -1 : 0);
     // t_delta (:285-291), first boundary (:294-296), t_max (:298-304)
@@ -334,26 +335,22 @@ voxel_trace_kernel(VoxDev d, const double* __restrict__ origin, const double* __
     double tm0 = st0 ? fabs(((double)(c0 + (st0 > 0 ? 1 : 0)) * res - s0) / d0) : INFINITY;
     double tm1 = st1 ? fabs(((double)(c1 + (st1 > 0 ? 1 : 0)) * res - s1) / d1) : INFINITY;
     double tm2 = st2 ? fabs(((double)(c2 + (st2 > 0 ? 1 : 0)) * res - s2) / d2) : INFINITY;
-    // the packed key moves with the walk: one signed increment per axis step (the walk may overshoot the end voxel
-    // by rounding, so it is bounded by `total <= dist` exactly as the reference's loop is, and by the range)
+    // The walk is kept as (a) the packed key, advanced by one signed per-axis increment per step, and (b) the signed
+    // step counts still to go per axis, r_a = (end_a - cur_a) * step_a: `cur != end_voxel` (:307) is r0|r1|r2 != 0,
+    // also after an overshoot (r_a < 0), exactly as the reference's tuple comparison.
     unsigned long long key = 0;
     vox_pack(c0, c1, c2, key);
     const unsigned long long k0 = (unsigned long long)((long long)st0 << 42), k1 = (unsigned long long)((long long)st1 << 21),
                              k2 = (unsigned long long)(long long)st2;
+    int r0 = (e0 - c0) * st0, r1 = (e1 - c1) * st1, r2 = (e2 - c2) * st2;
     out[len++] = key;
     double total = 0.0;
-    const int ilim = (int)kVoxBias - 1;
-    while ((c0 != e0 || c1 != e1 || c2 != e2) && total <= dist) {          // :307
-      const bool a0 = tm0 <= tm1 && tm0 <= tm2;                           // np.argmin(t_max): the first minimum
-      const bool a1 = !a0 && tm1 <= tm2;
-      const bool a2 = !a0 && !a1;
-      total = a0 ? tm0 : (a1 ? tm1 : tm2);
-      tm0 = a0 ? tm0 + td0 : tm0; tm1 = a1 ? tm1 + td1 : tm1; tm2 = a2 ? tm2 + td2 : tm2;
-      c0 += a0 ? st0 : 0; c1 += a1 ? st1 : 0; c2 += a2 ? st2 : 0;
-      key += a0 ? k0 : (a1 ? k1 : k2);
+    while ((r0 | r1 | r2) != 0 && total <= dist) {
       if (len >= max_len) { truncated = true; break; }
-      const bool inside = c0 >= -ilim - 1 && c0 <= ilim && c1 >= -ilim - 1 && c1 <= ilim && c2 >= -ilim - 1 && c2 <= ilim;
-      out[len++] = inside ? key : kVoxEmpty;
+      if (tm0 <= tm1 && tm0 <= tm2) { total = tm0; tm0 += td0; key += k0; --r0; }           // np.argmin: the first minimum
+      else if (tm1 <= tm2) { total = tm1; tm1 += td1; key += k1; --r1; }
+      else { total = tm2; tm2 += td2; key += k2; --r2; }
+      out[len++] = key;
     }
   } else if (stats != nullptr) {
     atomicAdd(&stats[1], 1);

@@ -199,9 +199,16 @@ class DeviceVoxelMap:
         updates = 0
         for lo in range(0, M, chunk):
             hi = min(M, lo + chunk)
-            d_o, d_d, d_dist, d_hit = (self.be.from_host(x[lo:hi]) for x in (o, d, dist, hit))
-            self.lib.voxel("update_rays", self.desc, self.be.ptr(d_o), self.be.ptr(d_d), self.be.ptr(d_dist), self.be.ptr(d_hit),
-                           hi - lo, float(like_hit), float(like_miss), self.be.ptr(ray_keys), self.be.ptr(ray_len), max_len,
+            n = hi - lo
+            # one upload per chunk: [origin 3n | direction 3n | distance n] float64, then hit n int32
+            packed = np.empty(7 * n * 8 + n * 4, dtype=np.uint8)
+            f64 = packed[:7 * n * 8].view(np.float64)
+            f64[:3 * n] = o[lo:hi].ravel(); f64[3 * n:6 * n] = d[lo:hi].ravel(); f64[6 * n:] = dist[lo:hi]
+            packed[7 * n * 8:].view(np.int32)[:] = hit[lo:hi]
+            d_in = self.be.from_host(packed)
+            base = self.be.ptr(d_in)
+            self.lib.voxel("update_rays", self.desc, base, base + 3 * n * 8, base + 6 * n * 8, base + 7 * n * 8,
+                           n, float(like_hit), float(like_miss), self.be.ptr(ray_keys), self.be.ptr(ray_len), max_len,
                            self.be.ptr(self._slot_rows), self.be.ptr(self._row_bits), self.be.ptr(stats), self.be.stream())
             st = self.be.to_host(stats)
             if int(st[1]) or int(st[2]):
