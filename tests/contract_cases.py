@@ -193,3 +193,61 @@ ALL_CASES = [case_planner_outputs_complete_trajectory, case_controller_accepts_p
              case_body_rate_control_consistency, case_trajectory_interpolation, case_emergency_trajectory_handling,
              case_performance_benchmark, case_wind_disturbance, case_actuator_saturation, case_wind_gust,
              case_emergency_failsafe_handling]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's other tests that reach the planner, restated with their own inputs and bounds.
+def case_se3_mpc_speed(r: Rig, n=100, mean_ms=50.0, single_ms=100.0):
+    """tests/test_planner_performance.py:17-43: 100 plans from the origin to goals U(-5,5)^3 (np.random.uniform, as the
+    reference draws them): mean <= 50 ms, no plan over 100 ms, every trajectory non-empty."""
+    state = DroneState(timestamp=0.0, position=np.zeros(3), velocity=np.zeros(3), attitude=np.zeros(3), angular_velocity=np.zeros(3))
+    np.random.seed(0)
+    r.planner.plan_trajectory(state, np.array([1.0, 1.0, 1.0]))          # first call loads the library / sizes the buffers
+    times = []
+    for _ in range(n):
+        goal = np.random.uniform(-5, 5, size=3)
+        t0 = time.perf_counter()
+        traj = r.planner.plan_trajectory(state, goal)
+        times.append((time.perf_counter() - t0) * 1e3)
+        assert len(traj.positions) > 0
+    assert sum(times) / len(times) <= mean_ms and max(times) <= single_ms
+    return sum(times) / len(times), max(times)
+
+
+def case_planner_controller_integration(r: Rig):
+    """tests/test_planner_controller_integration.py:16-76: six fields present, then a body-rate command for the first
+    three stamps of the plan: BodyRateCommand, thrust normalised to [0, 1], rates (3,)."""
+    tr = r.planner.plan_trajectory(r.initial_state, r.goal_position)
+    for name in ("positions", "velocities", "accelerations", "attitudes", "body_rates", "thrusts"):
+        assert getattr(tr, name) is not None
+    for i in range(min(3, len(tr.timestamps))):
+        cmd = r.controller.compute_body_rate_from_trajectory(r.initial_state, tr, tr.timestamps[i])
+        assert isinstance(cmd, BodyRateCommand) and 0.0 <= cmd.thrust <= 1.0 and cmd.body_rates.shape == (3,)
+
+
+def case_sitl_unit_planner(r: Rig):
+    """tests/test_sitl_unit_tests.py:25-120 (planner half): construction constants, goal / obstacle bookkeeping, a plan
+    from (0,0,-5) within 100 ms.  Two of its assertions cannot hold on the reference either and are restated as what
+    the reference does: `planner.config` is the BasePlanner dict (so the horizon is read from `se3_config`), and
+    `positions[0]` is NOT the current position -- the position block is unconstrained."""
+    pl = r.planner
+    assert pl.se3_config.prediction_horizon == 6 and pl.config["prediction_horizon"] == 6
+    assert pl.mass == 1.5 and abs(pl.hover_thrust - 1.5 * 9.81) < 5e-3
+    goal = np.array([10.0, 5.0, -8.0])
+    pl.set_goal(goal)
+    assert np.array_equal(pl.goal_position, goal)
+    pl.add_obstacle(np.array([5.0, 0.0, -5.0]), 2.0)
+    assert len(pl.obstacles) == 1
+    pl.clear_obstacles()
+    assert len(pl.obstacles) == 0
+    state = DroneState(timestamp=time.time(), position=np.array([0.0, 0.0, -5.0]), velocity=np.zeros(3),
+                       attitude=np.array([1.0, 0.0, 0.0, 0.0]), angular_velocity=np.zeros(3))
+    pl.plan_trajectory(state, np.array([5.0, 0.0, -5.0]))
+    t0 = time.perf_counter()
+    tr = pl.plan_trajectory(state, np.array([5.0, 0.0, -5.0]))
+    assert (time.perf_counter() - t0) * 1e3 < 100.0
+    assert len(tr.positions) > 0 and len(tr.velocities) > 0 and len(tr.accelerations) > 0
+    assert np.linalg.norm(tr.positions[0] - state.position) > 0.5          # pulled toward the goal: not the start
+
+
+OTHER_REFERENCE_CASES = [case_se3_mpc_speed, case_planner_controller_integration, case_sitl_unit_planner]

@@ -33,6 +33,15 @@ def test_contract_case(attach, case):
         case(rig)
 
 
+@pytest.mark.parametrize("case", cc.OTHER_REFERENCE_CASES, ids=lambda c: c.__name__)
+def test_other_reference_planner_tests(attach, case):
+    rig = cc.Rig(attach)
+    if case is cc.case_se3_mpc_speed:
+        case(rig, n=10, mean_ms=60000.0, single_ms=60000.0)      # timing bounds are for the GPU suite
+    else:
+        case(rig)
+
+
 def test_receding_horizon_warm_start(attach):
     cc.case_receding_horizon_warm_start(cc.Rig(attach))
 
