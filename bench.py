@@ -39,8 +39,8 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8192, help="rollouts per GPU per step (BASELINE.json metric: 8192)")
     ap.add_argument("--horizon", type=int, default=30)
     ap.add_argument("--ring", type=int, default=0, help="distinct batches cycled through (0 = enough to exceed 512 MiB)")

@@ -9,7 +9,7 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 COMMON="--no-cpu-baseline --no-solve --no-obstacle-source"
-# 1. kernel trace + stats of the default bench command (both legs, hipGraph replay, K = 2000)
+# 1. kernel trace + stats of the default bench command (both legs, hipGraph replay, K = 20000)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $COMMON > $OUT/bench_trace.log 2>&1
 # 2./3. PMC passes (their own runs, kernel-trace only; eager launches so every dispatch is a plain kernel)
 for C in FETCH_SIZE WRITE_SIZE; do
