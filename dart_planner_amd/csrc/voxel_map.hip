@@ -16,6 +16,8 @@
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
 
+static_assert(sizeof(se3mpc_voxel_map) == 48, "se3mpc_voxel_map is part of the C ABI (dart_planner_amd/capi.py mirrors it)");
+
 namespace se3mpc {
 
 struct VoxDev {

@@ -43,7 +43,7 @@ def test_library_loads_through_the_binding_without_a_gpu(lib_path):
     assert lib.default_params().as_dict() == capi.Params.reference_defaults().as_dict()
     assert lib.check_params(capi.Params.reference_defaults(horizon=65)) == -2
     assert lib.device_count() >= 0          # 0 on a CPU-only box; must not crash
-    assert ctypes.sizeof(capi.Params) == 160 and ctypes.sizeof(capi.SolveInfo) == 24
+    assert ctypes.sizeof(capi.Params) == 160 and ctypes.sizeof(capi.SolveInfo) == 24 and ctypes.sizeof(capi.VoxelMapDesc) == 48
 
 
 def test_missing_library_fails_loudly(tmp_path):
