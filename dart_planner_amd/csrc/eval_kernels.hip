@@ -916,6 +916,52 @@ transpose_kernel(int rows, int cols, const R* __restrict__ in, int ld_in, R* __r
   }
 }
 
+// Transpose of a matrix with one SMALL dimension (a decision-vector block: 9N <= 576 against a batch of thousands to
+// millions): out[c][r] = in[r][c].  The generic 64 x 64 tile reads or writes 256-B segments at a stride of 4 * 9N
+// bytes (1080 B at N = 30): misaligned partial lines on the narrow side.  Here a workgroup owns a strip of TW
+// consecutive indices of the LONG dimension and ALL indices of the short one, so the narrow side is one contiguous
+// run of TW * small elements, moved with full lines; the strip is staged in LDS with an odd row pitch (conflict-free
+// both ways).  ROWS_SMALL: in is [small][ld_in] (lane layout -> problem layout); else in is [long][ld_in].
+template <typename R, bool ROWS_SMALL>
+__global__ void __launch_bounds__(512)
+transpose_strip_kernel(int small, int longn, const R* __restrict__ in, int ld_in, R* __restrict__ out, int ld_out, int TW) {
+  HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  R* tile = reinterpret_cast<R*>(lds_raw);                  // [TW][pitch]: tile[t][s] = element (short index s, long index l0 + t)
+  const int pitch = small | 1;
+  const int l0 = blockIdx.x * TW;
+  const int nt = (longn - l0 < TW) ? longn - l0 : TW;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, nwave = blockDim.x / kWave;
+  constexpr int U = 8;                                      // independent loads in flight per lane
+  if constexpr (ROWS_SMALL) {
+    // read: one wavefront per short-index row, lanes along the long dimension (coalesced), TW <= 64
+    for (int s0 = wave * U; s0 < small; s0 += nwave * U) {
+      R v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = (s0 + u < small && lane < nt) ? in[(size_t)(s0 + u) * ld_in + l0 + lane] : (R)0;
+#pragma unroll
+      for (int u = 0; u < U; ++u) if (s0 + u < small && lane < nt) tile[lane * pitch + s0 + u] = v[u];
+    }
+    __syncthreads();
+    // write: one wavefront per output row (long index), lanes along the short dimension: consecutive rows are adjacent
+    for (int t = wave; t < nt; t += nwave)
+      for (int sidx = lane; sidx < small; sidx += kWave) out[(size_t)(l0 + t) * ld_out + sidx] = tile[t * pitch + sidx];
+  } else {
+    for (int t = wave; t < nt; t += nwave) {
+      const R* src = in + (size_t)(l0 + t) * ld_in;
+      for (int s0 = lane; s0 < small; s0 += kWave * U) {
+        R v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = (s0 + u * kWave < small) ? src[s0 + u * kWave] : (R)0;
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (s0 + u * kWave < small) tile[t * pitch + s0 + u * kWave] = v[u];
+      }
+    }
+    __syncthreads();
+    for (int sidx = wave; sidx < small; sidx += nwave)
+      if (lane < nt) out[(size_t)sidx * ld_out + l0 + lane] = tile[lane * pitch + sidx];
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host side: validation + launch
 // ------------------------------------------------------------------------------------------
@@ -1203,6 +1249,22 @@ int transpose_impl(int rows, int cols, const R* in, int ld_in, R* out, int ld_ou
   if (rows < 0 || cols < 0 || ld_in < cols || ld_out < rows) return SE3MPC_ERR_SHAPE;
   if (rows == 0 || cols == 0) return SE3MPC_OK;
   if (!in || !out) return SE3MPC_ERR_NULL;
+  // one small dimension (a decision-vector block against a batch): strip kernel with full-line traffic on both sides
+  const int small = rows < cols ? rows : cols, longn = rows < cols ? cols : rows;
+  if (small <= 9 * SE3MPC_MAX_HORIZON && longn >= 256) {
+    int TW = 64;
+    while (TW > 16 && (size_t)TW * (small | 1) * sizeof(R) > 72 * 1024) TW /= 2;
+    const size_t lds = (size_t)TW * (small | 1) * sizeof(R);
+    if (lds <= 72 * 1024) {
+      if (rows < cols)
+        hipLaunchKernelGGL((transpose_strip_kernel<R, true>), dim3(grid_for(longn, TW)), dim3(512), lds, (hipStream_t)stream, small,
+                           longn, in, ld_in, out, ld_out, TW);
+      else
+        hipLaunchKernelGGL((transpose_strip_kernel<R, false>), dim3(grid_for(longn, TW)), dim3(512), lds, (hipStream_t)stream, small,
+                           longn, in, ld_in, out, ld_out, TW);
+      return launch_status("se3mpc_transpose(strip)");
+    }
+  }
   hipLaunchKernelGGL(transpose_kernel<R>, dim3(grid_for(cols, 64), grid_for(rows, 64)), dim3(256), 0,
                      (hipStream_t)stream, rows, cols, in, ld_in, out, ld_out);
   return launch_status("se3mpc_transpose");

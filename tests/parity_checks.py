@@ -356,3 +356,13 @@ def check_population_sums(h: Harness, rows=90, B=1000, seed=0):
     assert np.allclose(out[:rows], (Xd * w).sum(1), rtol=1e-11, atol=1e-9) and np.isclose(out[rows], w.sum(), rtol=1e-12)
     out = h.to_host(h.ops.population_sums(dX, B=0))
     assert np.all(out == 0)
+
+
+def check_transpose(h: Harness, shapes=((270, 300), (300, 270), (54, 1000), (1000, 54), (576, 257), (257, 576), (5, 4096), (4096, 5),
+                                        (70, 70), (1, 256), (256, 1), (90, 255))):
+    """se3mpc_transpose_*: the strip kernel (one small dimension against >= 256) both ways, ragged last strips, and the
+    generic 64 x 64 tile -- bit-exact."""
+    rng = np.random.default_rng(12)
+    for rows, cols in shapes:
+        a = rng.normal(size=(rows, cols)).astype(h.dt)
+        assert np.array_equal(h.to_host(h.ops.transpose(h.to_dev(a))), a.T), (rows, cols)

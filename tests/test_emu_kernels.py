@@ -72,6 +72,11 @@ def test_solver_edge_inputs(emu_ops, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_transpose(emu_ops, dt):
+    pc.check_transpose(harness(emu_ops, dt), shapes=((270, 300), (300, 270), (576, 257), (257, 576), (5, 512), (512, 5), (70, 70), (90, 255)))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_population_sums(emu_ops, dt):
     pc.check_population_sums(harness(emu_ops, dt), rows=18, B=333)
 

@@ -37,6 +37,12 @@ def test_lane_kernels(gpu_ops, dt, N, B):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_transpose(gpu_ops, dt):
+    pc.check_transpose(harness(gpu_ops, dt))
+    pc.check_transpose(harness(gpu_ops, dt), shapes=((270, 100003), (100003, 270), (450, 8192)))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("rows,B", [(90, 8192), (150, 200001), (3, 64)])
 def test_population_sums(gpu_ops, dt, rows, B):
     pc.check_population_sums(harness(gpu_ops, dt), rows=rows, B=B, seed=rows)
