@@ -180,6 +180,7 @@ __global__ void obstacle_residual_kernel(DevParams<R> q, int B, int ld, const R*
   const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N;
   R mn = INFINITY, vs = 0;
+#pragma unroll 2
   for (int k = 0; k < N; ++k) {
     const R px = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * k + 0) * rowb);
     const R py = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * k + 1) * rowb);
@@ -196,6 +197,87 @@ __global__ void obstacle_residual_kernel(DevParams<R> q, int B, int ld, const R*
   if (viol != nullptr) viol[b] = vs;
 }
 
+// a9 reduced in-kernel (no N*K residuals written): min residual and summed violation per trajectory.  The N*K
+// distance evaluations are the cost (VALU-bound, not HBM-bound): positions are held in registers four steps at a
+// time, the sphere table is walked in pairs (two broadcast 16-B LDS reads per 8 evaluations) and f32 evaluates the
+// pair with packed instructions.  The table is padded to an even count with a residual-+inf row; steps past the
+// horizon are given a +inf position (residual +inf: neither the minimum nor the violation moves).
+template <typename R>
+__global__ void obstacle_reduce_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R* __restrict__ spheres,
+                                       int K, R* __restrict__ cmin, R* __restrict__ viol) {
+  __shared__ R sph[(SE3MPC_MAX_SPHERES + 2) * 4];
+  const int Kpad = (K + 1) & ~1;
+  for (int i = threadIdx.x; i < Kpad; i += blockDim.x) {
+    const bool real = i < K;
+    const R s = real ? spheres[4 * i + 3] + q.margin : (R)0;
+    sph[4 * i + 0] = real ? spheres[4 * i + 0] : (R)0;
+    sph[4 * i + 1] = real ? spheres[4 * i + 1] : (R)0;
+    sph[4 * i + 2] = real ? spheres[4 * i + 2] : (R)0;
+    sph[4 * i + 3] = real ? s * s : (R)-INFINITY;
+  }
+  __syncthreads();
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const int b = li.b;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int N = q.N;
+  const LaneBuf<R> xb = lane_buf(X);
+  constexpr int S = 4;
+  R mn = INFINITY;
+  if constexpr (sizeof(R) == 4) {
+    typedef float f2 __attribute__((vector_size(8)));
+    f2 vs2 = {0.0f, 0.0f};
+    for (int k0 = 0; k0 < N; k0 += S) {
+      float px[S], py[S], pz[S];
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int k = (k0 + u < N) ? k0 + u : N - 1;
+        px[u] = lane_ld<2>(xb, voff, (unsigned)(3 * k + 0) * rowb);
+        py[u] = lane_ld<2>(xb, voff, (unsigned)(3 * k + 1) * rowb);
+        pz[u] = lane_ld<2>(xb, voff, (unsigned)(3 * k + 2) * rowb);
+        if (k0 + u >= N) px[u] = INFINITY;
+      }
+      for (int j = 0; j < Kpad; j += 2) {
+        const R* s0 = sph + 4 * j;
+        const f2 cx = {s0[0], s0[4]}, cy = {s0[1], s0[5]}, cz = {s0[2], s0[6]}, r2 = {s0[3], s0[7]};
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+          const f2 dx = f2{px[u], px[u]} - cx, dy = f2{py[u], py[u]} - cy, dz = f2{pz[u], pz[u]} - cz;
+          const f2 cj = (dx * dx + dy * dy + dz * dz) - r2;                  // planner.py:508-512
+          mn = fminf(mn, fminf(cj[0], cj[1]));
+          vs2 += f2{fmaxf(0.0f, -cj[0]), fmaxf(0.0f, -cj[1])};
+        }
+      }
+    }
+    if (viol != nullptr) viol[b] = vs2[0] + vs2[1];
+  } else {
+    R vs = (R)0;
+    for (int k0 = 0; k0 < N; k0 += S) {
+      R px[S], py[S], pz[S];
+#pragma unroll
+      for (int u = 0; u < S; ++u) {
+        const int k = (k0 + u < N) ? k0 + u : N - 1;
+        px[u] = lane_ld<2>(xb, voff, (unsigned)(3 * k + 0) * rowb);
+        py[u] = lane_ld<2>(xb, voff, (unsigned)(3 * k + 1) * rowb);
+        pz[u] = lane_ld<2>(xb, voff, (unsigned)(3 * k + 2) * rowb);
+        if (k0 + u >= N) px[u] = INFINITY;
+      }
+      for (int j = 0; j < Kpad; ++j) {
+        const R cx = sph[4 * j], cy = sph[4 * j + 1], cz = sph[4 * j + 2], r2 = sph[4 * j + 3];
+#pragma unroll
+        for (int u = 0; u < S; ++u) {
+          const R dx = px[u] - cx, dy = py[u] - cy, dz = pz[u] - cz;
+          const R cj = (dx * dx + dy * dy + dz * dz) - r2;
+          mn = fmin(mn, cj);
+          vs += fmax((R)0, -cj);
+        }
+      }
+    }
+    if (viol != nullptr) viol[b] = vs;
+  }
+  if (cmin != nullptr) cmin[b] = mn;
+}
+
 // ------------------------------------------------------------------------------------------
 // a10: physical feasibility constraints (planner.py:472-497)
 // ------------------------------------------------------------------------------------------
@@ -207,6 +289,7 @@ __global__ void physical_constraints_kernel(DevParams<R> q, int B, int ld, const
   (void)b;
   const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
+#pragma unroll 4
   for (int k = 0; k < N; ++k) {
     R v2 = 0, a2 = 0, t2 = 0;
     for (int a = 0; a < 3; ++a) {
@@ -280,6 +363,7 @@ __global__ void extract_kernel(DevParams<R> q, int B, int ld, const R* __restric
   AttitudeState<R> prev;
   prev.valid = false;
   for (int i = 0; i < 3; ++i) prev.b1[i] = prev.b2[i] = prev.b3[i] = (R)0;
+#pragma unroll 2
   for (int k = 0; k < N; ++k) {
     R t[3];
     for (int a = 0; a < 3; ++a) t[a] = lane_ld<2>(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
@@ -739,26 +823,31 @@ rollout_lds_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, cons
 // ------------------------------------------------------------------------------------------
 // a16: is_plan_valid (planner.py:717-737)
 // ------------------------------------------------------------------------------------------
-template <typename R>
+template <typename R, bool HASV>
 __global__ void is_plan_valid_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ P, const R* __restrict__ V,
                                      int32_t* __restrict__ valid) {
   const LaneIdx li = lane_index<R>(B);
   if (!li.live) return;
   const int b = li.b;
-  (void)b;
   const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N;
+  const LaneBuf<R> pb = lane_buf(P), vb = lane_buf(HASV ? V : P);
   bool ok = true;
+  // loads first, tests after, no data-dependent branch: a block of rows is in flight per lane
+#pragma unroll 4
   for (int k = 0; k < N; ++k) {
+    R x[3], v[3];
+#pragma unroll
     for (int a = 0; a < 3; ++a) {
-      const R x = lane_ld<2>(lane_buf(P), voff, (unsigned)(3 * k + a) * rowb);
-      if (isnan(x) || isinf(x)) ok = false;                            // planner.py:724
-      if (a == 2 && x < (R)0.1) ok = false;                            // planner.py:728
-      if (V != nullptr) {
-        const R v = lane_ld<2>(lane_buf(V), voff, (unsigned)(3 * k + a) * rowb);
-        if (fabs(v) > (R)20.0) ok = false;                             // planner.py:734
-      }
+      x[a] = lane_ld<2>(pb, voff, (unsigned)(3 * k + a) * rowb);
+      if constexpr (HASV) v[a] = lane_ld<2>(vb, voff, (unsigned)(3 * k + a) * rowb);
     }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      ok = ok & (fabs(x[a]) < (R)INFINITY);                            // planner.py:724 (NaN and +-Inf fail the comparison)
+      if constexpr (HASV) ok = ok & !(fabs(v[a]) > (R)20.0);           // planner.py:734
+    }
+    ok = ok & !(x[2] < (R)0.1);                                        // planner.py:728
   }
   valid[b] = ok ? 1 : 0;
 }
@@ -1022,8 +1111,12 @@ int obstacle_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, co
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || (K > 0 && !spheres)) return SE3MPC_ERR_NULL;
-  hipLaunchKernelGGL(obstacle_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
-                     (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, spheres, K, C, cmin, viol);
+  if (C == nullptr)
+    hipLaunchKernelGGL(obstacle_reduce_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                       make_dev_params<R>(*p), B, ld, X, spheres, K, cmin, viol);
+  else
+    hipLaunchKernelGGL(obstacle_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
+                       (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, spheres, K, C, cmin, viol);
   return launch_status("se3mpc_obstacle_residual");
 }
 
@@ -1187,8 +1280,12 @@ int is_plan_valid_impl(const se3mpc_params* p, int B, int ld, const R* P, const 
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!P || !valid) return SE3MPC_ERR_NULL;
-  hipLaunchKernelGGL(is_plan_valid_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
-                     make_dev_params<R>(*p), B, ld, P, V, valid);
+  if (V != nullptr)
+    hipLaunchKernelGGL((is_plan_valid_kernel<R, true>), dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                       make_dev_params<R>(*p), B, ld, P, V, valid);
+  else
+    hipLaunchKernelGGL((is_plan_valid_kernel<R, false>), dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                       make_dev_params<R>(*p), B, ld, P, V, valid);
   return launch_status("se3mpc_is_plan_valid");
 }
 

@@ -101,6 +101,14 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
     vec_close(h.unlane(Cm, (B, N * 16)), Cref, t["vec_rel"], "obstacle residual")
     vec_close(h.to_host(cmin), Cref.min(1), t["vec_rel"], "obstacle min")
     vec_close(h.to_host(viol), np.maximum(0, -Cref).sum(1), t["vec_rel"] * 4, "obstacle violation")
+    # reduced in-kernel (no residuals written): its own kernel; odd sphere counts exercise the padding row
+    for Ks in (16, 7, 1):
+        _, cmin_r, viol_r = h.ops.obstacle_residual(prm, h.lane(X, B), h.prob(sph[:Ks]), materialize=False)
+        Cr_k = Cref.reshape(B, N, 16)[:, :, :Ks].reshape(B, -1)
+        vec_close(h.to_host(cmin_r), Cr_k.min(1), t["vec_rel"], f"obstacle min (reduced, K={Ks})")
+        vec_close(h.to_host(viol_r), np.maximum(0, -Cr_k).sum(1), t["vec_rel"] * 4, f"obstacle violation (reduced, K={Ks})")
+    _, cmin_e, viol_e = h.ops.obstacle_residual(prm, h.lane(X, B), h.prob(np.zeros((0, 4))), materialize=False)
+    assert np.all(np.isinf(h.to_host(cmin_e))) and np.all(h.to_host(viol_e) == 0)
     C0, cmin0, viol0 = h.ops.obstacle_residual(prm, h.lane(X, B), h.prob(np.zeros((0, 4))))
     assert tuple(C0.shape) == (0, B) and np.all(np.isinf(h.to_host(cmin0))) and np.all(h.to_host(viol0) == 0)
     # a10
