@@ -132,6 +132,7 @@ _VOXEL_PLAIN_API = {
     "se3mpc_voxel_insert": (C.c_int, [_VP, _P, _P, _D, _P, _I, _P, _P]),
     "se3mpc_voxel_update_rays": (C.c_int, [_VP, _P, _P, _P, _P, _I, _D, _D, _P, _P, _I, _P, _P, _P, _P]),
     "se3mpc_voxel_update_row_words": (C.c_longlong, [_I, _I]),
+    "se3mpc_voxel_trace_rays": (C.c_int, [_VP, _P, _P, _P, _I, _P, _P, _I, _P, _P]),
     "se3mpc_voxel_export": (C.c_int, [_VP, _P, _P, _P, _P, _P]),
     "se3mpc_voxel_local_workspace": (C.c_int, [_I]),
 }

@@ -584,6 +584,23 @@ extern "C" int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double*
   return launch_status("se3mpc_voxel_update_rays(apply)");
 }
 
+extern "C" int se3mpc_voxel_trace_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
+                                       const double* distance, int M, uint64_t* ray_keys, int32_t* ray_len, int max_len,
+                                       int32_t* stats, void* stream) {
+  VoxDev d;
+  int rc = make_vox_dev(m, d);
+  if (rc) return rc;
+  if (M < 0 || max_len < 1 || (long long)M * max_len >= (1ll << 31)) return SE3MPC_ERR_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  if (stats != nullptr && hipMemsetAsync(stats, 0, 4 * sizeof(int32_t), s) != hipSuccess)
+    return launch_status("se3mpc_voxel_trace_rays(memset)");
+  if (M == 0) return SE3MPC_OK;
+  if (!origin || !direction || !distance || !ray_keys || !ray_len) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(voxel_trace_kernel, dim3(grid_for(M, 64)), dim3(64), 0, s, d, origin, direction, distance, M,
+                     reinterpret_cast<unsigned long long*>(ray_keys), ray_len, max_len, stats);
+  return launch_status("se3mpc_voxel_trace_rays");
+}
+
 extern "C" long long se3mpc_voxel_update_row_words(int M, int max_len) {
   if (M < 1 || max_len < 1) return 0;
   return (long long)M * max_len * 2 * ((M + 63) / 64);

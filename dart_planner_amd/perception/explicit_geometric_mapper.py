@@ -83,6 +83,13 @@ class ExplicitGeometricMapper:
         return {"updated_voxels": updated, "total_voxels": total, "update_time_ms": (time.time() - t0) * 1000,
                 "observations_processed": n}
 
+    # ------------------------------------------------------------------ mapper.py:251-312
+    def _trace_ray(self, start, direction, distance: float) -> List[Tuple[int, int, int]]:
+        direction = np.asarray(direction, float)
+        direction = direction / np.linalg.norm(direction)                                           # :265
+        vox = self.map.trace_rays([np.asarray(to_float(start), float)], [direction], [float(distance)])[0]
+        return [(int(a), int(b), int(c)) for a, b, c in vox]
+
     # ------------------------------------------------------------------ mapper.py:155-193
     def query_occupancy(self, position) -> float:
         self.total_queries += 1

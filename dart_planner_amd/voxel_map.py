@@ -172,6 +172,34 @@ class DeviceVoxelMap:
                        float(radius), self.be.ptr(spheres), cap, self.be.ptr(count), self.be.ptr(work), self.be.stream())
         return spheres, count
 
+    def trace_rays(self, origins, unit_directions, distances):
+        """_trace_ray (mapper.py:251-312) for M rays on the device -> list of (len_i, 3) int64 index arrays in walk order."""
+        o = np.ascontiguousarray(np.asarray(origins, np.float64).reshape(-1, 3))
+        d = np.ascontiguousarray(np.asarray(unit_directions, np.float64).reshape(-1, 3))
+        dist = np.ascontiguousarray(np.asarray(distances, np.float64).reshape(-1))
+        M = len(dist)
+        if M == 0:
+            return []
+        max_len = 3 * int(np.ceil(float(np.max(dist)) / self.resolution)) + 8
+        ray_keys = self.be.empty((M, max_len), "i64")
+        ray_len = self.be.empty((M,), "i32")
+        stats = self.be.empty((4,), "i32")
+        d_o, d_d, d_dist = (self.be.from_host(x) for x in (o, d, dist))
+        self.lib.voxel("trace_rays", self.desc, self.be.ptr(d_o), self.be.ptr(d_d), self.be.ptr(d_dist), M, self.be.ptr(ray_keys),
+                       self.be.ptr(ray_len), max_len, self.be.ptr(stats), self.be.stream())
+        st = self.be.to_host(stats)
+        if int(st[1]) or int(st[2]):
+            raise RuntimeError(f"ray walk dropped work: {int(st[1])} rays outside the index range, {int(st[2])} truncated")
+        keys = np.array(self.be.to_host(ray_keys)).view(np.uint64)
+        lens = np.array(self.be.to_host(ray_len))
+        out = []
+        for r in range(M):
+            k = keys[r, :lens[r]]
+            out.append(np.stack([((k >> np.uint64(42)) & np.uint64(0x1FFFFF)).astype(np.int64) - (1 << 20),
+                                 ((k >> np.uint64(21)) & np.uint64(0x1FFFFF)).astype(np.int64) - (1 << 20),
+                                 (k & np.uint64(0x1FFFFF)).astype(np.int64) - (1 << 20)], axis=1))
+        return out
+
     # ------------------------------------------------------------------ update_map
     def update_rays(self, origins, unit_directions, distances, hits, like_hit: float = 0.7, like_miss: float = 0.6):
         """update_map (mapper.py:102-153) for M observations in order (chunks of at most 1024 rays per launch group).

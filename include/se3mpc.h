@@ -305,6 +305,13 @@ int se3mpc_voxel_update_rays(const se3mpc_voxel_map* m, const double* origin, co
                              uint64_t* ray_keys, int32_t* ray_len, int max_len, int32_t* slot_rows, uint64_t* row_bits,
                              int32_t* stats, void* stream);
 long long se3mpc_voxel_update_row_words(int M, int max_len);
+/* _trace_ray (mapper.py:251-312) alone, for M rays: ray_keys[ray][0 .. ray_len[ray]) = the packed indices of the
+ * walked voxels in walk order (index a = ((key >> (42 - 21 a)) & 0x1FFFFF) - 2^20 for a = 0, 1, 2; SE3MPC_VOXEL_EMPTY
+ * for a voxel outside the packable range).  The table is not touched (only m->resolution is used).  stats as in
+ * se3mpc_voxel_update_rays ([0] voxels walked, [1] rays dropped, [2] rays truncated). */
+int se3mpc_voxel_trace_rays(const se3mpc_voxel_map* m, const double* origin, const double* direction,
+                            const double* distance, int M, uint64_t* ray_keys, int32_t* ray_len, int max_len,
+                            int32_t* stats, void* stream);
 /* Compact the occupied slots (order unspecified): ijk_out [capacity][3], prob_out / count_out [capacity] (may be
  * NULL), *n_out = number of voxels (the caller zeroes nothing: the function resets *n_out itself). */
 int se3mpc_voxel_export(const se3mpc_voxel_map* m, int32_t* ijk_out, double* prob_out, int32_t* count_out,

@@ -1,5 +1,6 @@
 """pytest plugin (TEST INFRASTRUCTURE, build container only): lets the reference's own
-tests/test_planner_controller_contract.py run *in place, unchanged* against this package on a box
+tests/test_planner_controller_contract.py (and test_mapper_trace_ray.py, test_se3_mpc_with_mapper.py,
+test_planner_performance.py, test_planner_controller_integration.py) run *in place, unchanged* against this package on a box
 without a GPU by pointing the planner at the host-emulated kernels.  Usage:
 
   PYTHONPATH=dart_planner_amd/compat:.:tests/emu python -m pytest -c /dev/null --rootdir=/tmp \
@@ -16,3 +17,11 @@ def pytest_configure(config):
     from dart_planner_amd.planning import se3_mpc_planner as mod
     ops = Ops(TorchCpuBackend(), capi.Library(build_emu.build()))
     mod.SE3MPCPlanner._get_ops = lambda self: ops
+    # the mapper mirror builds its device table through Ops(): hand it the emulated library too
+    from dart_planner_amd import voxel_map
+    real_init = voxel_map.DeviceVoxelMap.__init__
+
+    def init_with_emulated_ops(self, *a, **k):
+        k["ops"] = k.get("ops") or ops
+        real_init(self, *a, **k)
+    voxel_map.DeviceVoxelMap.__init__ = init_with_emulated_ops

@@ -37,6 +37,7 @@ def test_scene_matches_reference_mapper(emu_ops, golden_map, scene):
 
 def test_ray_walk_matches_reference(emu_ops, golden_map):
     vc.check_trace_rays(emu_ops, *golden_map)
+    vc.check_trace_ray_method(emu_ops, *golden_map)
 
 
 def test_edges_and_statuses(emu_ops):

@@ -38,6 +38,7 @@ def test_scene_matches_reference_mapper(gpu_ops, golden_map, scene):
 
 def test_ray_walk_matches_reference(gpu_ops, golden_map):
     vc.check_trace_rays(gpu_ops, *golden_map)
+    vc.check_trace_ray_method(gpu_ops, *golden_map)
 
 
 def test_edges_and_statuses(gpu_ops):

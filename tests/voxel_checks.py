@@ -81,6 +81,19 @@ def check_scene(ops, data, sc, capacity=64, max_grid_cells=None):
     return m
 
 
+def check_trace_ray_method(ops, data, meta):
+    """_trace_ray itself (the method the reference's tests/test_mapper_trace_ray.py calls), every golden ray in walk
+    order, and that test's own assertion (6-connected, no gaps)."""
+    for r in meta["rays"]:
+        m = ExplicitGeometricMapper(resolution=r["resolution"], max_range=50.0, capacity=64, ops=ops)
+        vox = m._trace_ray(np.array(r["start"], float), np.array(r["direction"], float), r["distance"])
+        assert np.array_equal(np.array(vox, dtype=np.int64).reshape(-1, 3), data[r["key"] + "voxels"]), r
+    m = ExplicitGeometricMapper(resolution=0.5, ops=ops)
+    voxels = m._trace_ray(np.array([0.0, 0.0, 0.0]), np.array([1.0, 1.0, 0.0]) / np.sqrt(2), distance=5.0)
+    diffs = [np.sum(np.abs(np.subtract(v2, v1))) for v1, v2 in zip(voxels[:-1], voxels[1:])]
+    assert all(d == 1 for d in diffs)
+
+
 def check_trace_rays(ops, data, meta):
     """_trace_ray (mapper.py:251-312) through update_map on an empty map: one pass-through ray marks exactly the
     voxels the reference's walk returns, each once."""
