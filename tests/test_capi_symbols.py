@@ -61,3 +61,16 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or re.search(r"#include\s+[<\"].*oracle", txt):
                     bad.append(os.path.join(d, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/se3mpc.h is the drop-in boundary: it must compile as C99 (no C++ or torch types in the signatures)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "se3mpc.h"\nint main(void) { se3mpc_params p; se3mpc_voxel_map m; se3mpc_solve_info i;\n'
+                   '  (void)p; (void)m; (void)i; return se3mpc_abi_version() == SE3MPC_ABI_VERSION ? 0 : 1; }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                    str(src)], check=True)
