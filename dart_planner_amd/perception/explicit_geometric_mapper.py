@@ -83,6 +83,28 @@ class ExplicitGeometricMapper:
         return {"updated_voxels": updated, "total_voxels": total, "update_time_ms": (time.time() - t0) * 1000,
                 "observations_processed": n}
 
+    def update_map_arrays(self, origins, directions, hit_distances, max_ranges=None) -> Dict[str, Any]:
+        """update_map for a scan that already is arrays (a LiDAR driver's output): origins (M, 3) or (3,), directions
+        (M, 3) not necessarily normalised, hit_distances (M,) with NaN = no return, max_ranges (M,) or a scalar
+        (default: the map's max_range).  Same arithmetic and result as update_map on the equivalent observations."""
+        t0 = time.time()
+        d = np.asarray(directions, float).reshape(-1, 3)
+        n = len(d)
+        o = np.broadcast_to(np.asarray(to_float(origins), float).reshape(-1, 3), (n, 3))
+        h = np.asarray(hit_distances, float).reshape(-1)
+        mr = np.broadcast_to(np.asarray(self.max_range if max_ranges is None else max_ranges, float).reshape(-1), (n,))
+        if n:
+            unit = np.array([v / np.linalg.norm(v) for v in d])                                      # :265, one ray at a time as the reference
+            has = ~np.isnan(h)
+            dist = np.minimum(np.where(has & (h != 0.0), h, mr), self.max_range)                      # `if obs.hit_distance` (:111-112)
+            updated, total = self.map.update_rays(o, unit, dist, has.astype(np.int32), self.prob_hit, 1 - self.prob_miss)
+        else:
+            updated, total = 0, len(self.map)
+        self.total_observations += n
+        self.last_update_time = time.time()
+        return {"updated_voxels": updated, "total_voxels": total, "update_time_ms": (time.time() - t0) * 1000,
+                "observations_processed": n}
+
     # ------------------------------------------------------------------ mapper.py:251-312
     def _trace_ray(self, start, direction, distance: float) -> List[Tuple[int, int, int]]:
         direction = np.asarray(direction, float)

@@ -15,7 +15,7 @@ def observations(data, scan):
             for o, d, h in zip(data[k + "origin"], data[k + "dirs"], data[k + "hits"])]
 
 
-def check_scene(ops, data, sc, capacity=64, max_grid_cells=None):
+def check_scene(ops, data, sc, capacity=64, max_grid_cells=None, array_form=True):
     """One golden scene end to end: add_obstacle, update_map scan by scan, queries, trajectory safety, local grids."""
     k = sc["key"]
     m = ExplicitGeometricMapper(resolution=sc["resolution"], max_range=sc["max_range"], capacity=capacity, ops=ops)
@@ -31,6 +31,16 @@ def check_scene(ops, data, sc, capacity=64, max_grid_cells=None):
         assert np.array_equal(cnt, data[s["key"] + "count"]), s["key"]
         assert np.array_equal(prob, data[s["key"] + "prob"]), s["key"]                 # bit-exact float64
     assert m.get_mapping_stats()["total_voxels"] == len(data[sc["scans"][-1]["key"] + "keys"])
+    # the array form of update_map gives the same map
+    m2 = None if not array_form else ExplicitGeometricMapper(resolution=sc["resolution"], max_range=sc["max_range"], capacity=capacity, ops=ops)
+    if m2 is not None:
+        for c, r in sc["obstacles"]:
+            m2.add_obstacle(np.array(c, float), r)
+        for s in sc["scans"]:
+            res2 = m2.update_map_arrays(data[s["key"] + "origin"], data[s["key"] + "dirs"], data[s["key"] + "hits"], s["obs_max_range"])
+            assert res2["updated_voxels"] == s["updated_voxels"]
+        for a, b in zip(m2.map.items(), m.map.items()):
+            assert np.array_equal(a, b)
     # point queries
     q = data[k + "query_pos"]
     assert np.array_equal(m.query_occupancy_batch(q), data[k + "query_occ"])
