@@ -32,8 +32,8 @@ def golden_map():
 @pytest.mark.parametrize("scene", [0, 1, 2])
 def test_scene_matches_reference_mapper(emu_ops, golden_map, scene):
     data, meta = golden_map
-    # (scene 1 = 456 rays at 0.2 m: the array form is re-checked on the other two here and on all three on the GPU)
-    vc.check_scene(emu_ops, data, meta["scenes"][scene], max_grid_cells=70_000, array_form=scene != 1)
+    # (the array form of update_map is re-checked on the edge-case scene here and on all three on the GPU)
+    vc.check_scene(emu_ops, data, meta["scenes"][scene], max_grid_cells=70_000, array_form=scene == 2)
 
 
 def test_ray_walk_matches_reference(emu_ops, golden_map):
