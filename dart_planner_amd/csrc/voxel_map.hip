@@ -428,6 +428,10 @@ voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_slots, c
   unsigned long long* bits = row_bits + (size_t)j * (size_t)(2 * W);
   double p = d.prob[sl];
   int n = 0;
+  // The update is a pure function of (p, kind): once a kind of update leaves p unchanged it will do so again at this
+  // p (the clamp makes 0.99 / 0.01 such fixed points -- the sensor's own voxel saturates after a dozen pass-throughs and
+  // is then touched by every remaining ray).  A kind known to be idle is skipped; when both are, the rest is a popcount.
+  bool idle_hit = false, idle_miss = false;
   for (int w = 0; w < W; ++w) {
     unsigned long long touched = bits[w];
     const unsigned long long hits = bits[W + w];
@@ -435,7 +439,18 @@ voxel_apply_kernel(VoxDev d, const unsigned long long* __restrict__ ray_slots, c
     bits[W + w] = 0ull;
     while (touched != 0ull) {
       const unsigned long long lowest = touched & (0ull - touched);
-      p = vox_bayes(p, (hits & lowest) ? like_hit : like_miss);
+      const bool is_hit = (hits & lowest) != 0ull;
+      if (is_hit ? idle_hit : idle_miss) {
+        // an idle kind: take the whole run of it, up to the next update of the other kind, in one step
+        const unsigned long long other = is_hit ? (touched & ~hits) : (touched & hits);
+        const unsigned long long run = other != 0ull ? (touched & ((other & (0ull - other)) - 1ull)) : touched;
+        n += __builtin_popcountll(run);
+        touched ^= run;
+        continue;
+      }
+      const double pn = vox_bayes(p, is_hit ? like_hit : like_miss);
+      if (pn == p) { if (is_hit) idle_hit = true; else idle_miss = true; }
+      else { idle_hit = false; idle_miss = false; p = pn; }
       ++n;
       touched ^= lowest;
     }
