@@ -243,7 +243,7 @@ __device__ __forceinline__ bool grid_cell_occupied(const VoxDev& d, const GridDe
 }
 
 __global__ void __launch_bounds__(256)
-voxel_grid_count_kernel(VoxDev d, GridDev g, int32_t* __restrict__ run_counts) {
+voxel_grid_count_kernel(VoxDev d, GridDev g, int32_t* __restrict__ run_counts, unsigned long long* __restrict__ masks) {
   HIP_DYNAMIC_SHARED(int, ax)
   grid_stage_axes(d, g, ax);
   const int lane = lane_id();
@@ -255,17 +255,17 @@ voxel_grid_count_kernel(VoxDev d, GridDev g, int32_t* __restrict__ run_counts) {
     const long long m = base + r * kWave + lane;
     int ix, iy, iz;
     const bool o = m < g.M && grid_cell_occupied(d, g, ax, m, ix, iy, iz);
-    cnt += __builtin_popcountll(wave_ballot(o));
+    const uint64_t mask = wave_ballot(o);
+    if (lane == 0) masks[run * (kGridRun / kWave) + r] = mask;          // the second pass reads the answer instead of probing again
+    cnt += __builtin_popcountll(mask);
   }
   if (lane == 0) run_counts[run] = cnt;
 }
 
 template <typename R>
 __global__ void __launch_bounds__(256)
-voxel_grid_select_kernel(VoxDev d, GridDev g, const int32_t* __restrict__ run_counts, int nruns, R* __restrict__ spheres,
-                         int32_t* __restrict__ count) {
-  HIP_DYNAMIC_SHARED(int, ax)
-  grid_stage_axes(d, g, ax);
+voxel_grid_select_kernel(GridDev g, const int32_t* __restrict__ run_counts, const unsigned long long* __restrict__ masks,
+                         int nruns, R* __restrict__ spheres, int32_t* __restrict__ count) {
   const int lane = lane_id();
   const long long run = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
   const long long base = run * kGridRun;
@@ -281,14 +281,14 @@ voxel_grid_select_kernel(VoxDev d, GridDev g, const int32_t* __restrict__ run_co
   total = wave_sum_i32(total);
   const int step = (g.target > 0 && total / g.target > 1) ? total / g.target : 1;   // max(1, n_occupied // target)
   int rank = before;
+  const long long n = g.n;
   for (int r = 0; r < kGridRun / kWave; ++r) {
-    const long long m = base + r * kWave + lane;
-    int ix = 0, iy = 0, iz = 0;
-    const bool o = m < g.M && grid_cell_occupied(d, g, ax, m, ix, iy, iz);
-    const uint64_t mask = wave_ballot(o);
-    if (o) {
+    const uint64_t mask = masks[run * (kGridRun / kWave) + r];
+    if ((mask >> lane) & 1ull) {
       const int rk = rank + __builtin_popcountll(mask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
       if (rk % step == 0 && rk / step < g.cap) {
+        const long long m = base + r * kWave + lane;
+        const int iy = (int)(m % n), ix = (int)((m / n) % n), iz = (int)(m / (n * n));   // (iz, ix, iy), iy fastest
         R* s4 = spheres + (size_t)4 * (rk / step);
         s4[0] = (R)grid_axis_value(g, 0, ix); s4[1] = (R)grid_axis_value(g, 1, iy); s4[2] = (R)grid_axis_value(g, 2, iz);
         s4[3] = (R)g.radius;
@@ -521,10 +521,12 @@ int voxel_local_spheres_impl(const se3mpc_voxel_map* m, const double* centre, do
   const int nruns = grid_runs(g.M);
   const int nblk = grid_for(nruns, 4);
   const size_t lds = (size_t)3 * g.n * sizeof(int);
-  hipLaunchKernelGGL(voxel_grid_count_kernel, dim3(nblk), dim3(256), lds, s, d, g, workspace);
+  // workspace: [nruns run counts | pad to 8 B | nruns * 16 occupancy masks (one 64-bit ballot per 64 cells)]
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(workspace + ((nruns + 1) & ~1));
+  hipLaunchKernelGGL(voxel_grid_count_kernel, dim3(nblk), dim3(256), lds, s, d, g, workspace, masks);
   rc = launch_status("se3mpc_voxel_local_spheres(count)");
   if (rc) return rc;
-  hipLaunchKernelGGL(voxel_grid_select_kernel<R>, dim3(nblk), dim3(256), lds, s, d, g, workspace, nruns, spheres, count);
+  hipLaunchKernelGGL(voxel_grid_select_kernel<R>, dim3(nblk), dim3(256), 0, s, g, workspace, masks, nruns, spheres, count);
   return launch_status("se3mpc_voxel_local_spheres(select)");
 }
 
@@ -624,7 +626,8 @@ extern "C" long long se3mpc_voxel_update_row_words(int M, int max_len) {
 extern "C" int se3mpc_voxel_local_workspace(int cells_per_axis) {
   if (cells_per_axis < 1) return 1;
   const long long n = cells_per_axis;
-  return grid_runs(n * n * n) + 1;
+  const int nruns = grid_runs(n * n * n);
+  return ((nruns + 1) & ~1) + 2 * nruns * (kGridRun / kWave);            // run counts + one 64-bit mask per 64 cells
 }
 
 #define SE3MPC_DEFINE_VOXEL_API(SUF, R)                                                                                    \
