@@ -46,8 +46,15 @@ class Harness:
 
 
 def oracle_cfg(prm: Params) -> orc.OracleConfig:
+    """The oracle configuration that states the same problem as `prm`.  The reference couples ftol to gtol
+    (planner.py:264-265: ftol = 10 * convergence_tolerance), so only such pairs can be expressed."""
+    assert abs(prm.ftol - 10 * prm.pgtol) <= 1e-15 * max(1.0, abs(prm.ftol)), "the reference solves with ftol = 10 * gtol"
     return orc.OracleConfig(prediction_horizon=prm.horizon, dt=prm.dt, max_iterations=prm.max_iterations,
-                            convergence_tolerance=prm.pgtol)
+                            convergence_tolerance=prm.pgtol, max_velocity=prm.max_velocity, max_acceleration=prm.max_acceleration,
+                            max_thrust=prm.max_thrust, min_thrust=prm.min_thrust, max_tilt_angle=prm.max_tilt_angle,
+                            position_weight=prm.position_weight, velocity_weight=prm.velocity_weight,
+                            acceleration_weight=prm.acceleration_weight, thrust_weight=prm.thrust_weight,
+                            safety_margin=prm.safety_margin, mass=prm.mass, gravity=prm.gravity, position_bound=prm.position_bound)
 
 
 def vec_close(a, b, rel, what=""):

@@ -1,0 +1,59 @@
+"""GPU box: a larger random sweep of the batched solver against the oracle (SciPy, problem by problem on the host) than
+the test-suite runs: horizons 2..64, default and perturbed options.  Prints one JSON line per configuration and a total.
+usage: python tools/gpu_fuzz_solver.py [problems_per_config]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+import parity_checks as pc
+from dart_planner_amd.ops import Ops, TorchBackend
+
+ops = Ops(TorchBackend("cuda:0"))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+def harness(dt):
+    return pc.Harness(ops, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0"), lambda a: a.detach().cpu().numpy(), dt)
+# (the reference couples ftol = 10 * gtol, planner.py:264-265; the oracle can only state such pairs)
+configs = [(6, {}), (20, {}), (30, {}), (50, {}), (64, {}), (2, {}), (13, {}), (33, {}), (30, dict(max_iterations=40, pgtol=1e-3, ftol=1e-2)),
+           (6, dict(max_iterations=60, pgtol=1e-6, ftol=1e-5)), (20, dict(max_iterations=100, pgtol=1e-8, ftol=1e-7)), (20, dict(dt=0.05)),
+           (30, dict(max_velocity=3.0, position_bound=15.0)), (30, dict(max_thrust=18.0, min_thrust=6.0, max_tilt_angle=0.3)),
+           (20, dict(position_weight=3.0, velocity_weight=40.0, thrust_weight=2.5, acceleration_weight=0.2)),
+           (30, dict(max_iterations=2)), (30, dict(max_iterations=0))]
+from dart_planner_amd.capi import Params
+from oracle import se3mpc_oracle as orc
+
+
+def sweep(h, N, B, seed, **ov):
+    """As tests/parity_checks.check_solver_vs_oracle, but the position error is also taken over the problems whose
+    evaluation counts differ (a count can move by one in a 20-evaluation line search while x does not)."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N, **ov)
+    cfg = pc.oracle_cfg(prm)
+    p0, v0, goal, _ = pc.random_batch(rng, B, N)
+    out = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
+    info = h.ops.info_to_host(out["info"])
+    X = h.to_host(out["x"]).astype(float)
+    worst_same = worst_diff = 0.0
+    mism = []
+    for i in range(B):
+        xr, ir = orc.solve(p0[i].astype(h.dt).astype(float), v0[i].astype(h.dt).astype(float), goal[i].astype(h.dt).astype(float), cfg)
+        got = (int(info["nit"][i]), int(info["nfev"][i]), int(info["status"][i]))
+        err = float(np.max(np.abs(X[i, :3 * N] - xr[:3 * N])))
+        if got == (ir["nit"], ir["nfev"], ir["status"]):
+            worst_same = max(worst_same, err)
+        else:
+            worst_diff = max(worst_diff, err)
+            mism.append(dict(problem=i, kernel=got, scipy=(ir["nit"], ir["nfev"], ir["status"]), position_error_m=err))
+    return worst_same, worst_diff, mism
+
+
+tot = dict(problems=0, count_mismatches=0, worst_f64=0.0, worst_f32=0.0, worst_on_count_mismatch=0.0)
+t0 = time.time()
+for i, (N, ov) in enumerate(configs):
+    for dt, key in ((np.float64, "worst_f64"), (np.float32, "worst_f32")):
+        ws, wd, mism = sweep(harness(dt), N, B, 1000 + 17 * i, **ov)
+        tot["problems"] += B; tot["count_mismatches"] += len(mism); tot[key] = max(tot[key], ws)
+        tot["worst_on_count_mismatch"] = max(tot["worst_on_count_mismatch"], wd)
+        print(json.dumps(dict(horizon=N, options=ov, dtype=np.dtype(dt).name, problems=B, iteration_count_mismatches=len(mism),
+                              max_position_error_m=ws, mismatched=mism[:8])), flush=True)
+tot["seconds"] = round(time.time() - t0, 1)
+print(json.dumps(tot))
