@@ -41,6 +41,10 @@ def test_ray_walk_matches_reference(emu_ops, golden_map):
     vc.check_trace_ray_method(emu_ops, *golden_map)
 
 
+def test_random_scenes_match_oracle(emu_ops):
+    vc.check_random_scenes(emu_ops, n_scenes=2, n_rays=40)
+
+
 def test_edges_and_statuses(emu_ops):
     vc.check_edges(emu_ops)
 

@@ -41,6 +41,10 @@ def test_ray_walk_matches_reference(gpu_ops, golden_map):
     vc.check_trace_ray_method(gpu_ops, *golden_map)
 
 
+def test_random_scenes_match_oracle(gpu_ops):
+    vc.check_random_scenes(gpu_ops, n_scenes=16, n_rays=200)
+
+
 def test_edges_and_statuses(gpu_ops):
     vc.check_edges(gpu_ops)
 

@@ -202,3 +202,38 @@ def check_restarts_filtered_by_map(ops, planner_factory, n_restarts=48):
         ok, first = m2.is_trajectory_safe(P, 1.0, 0.6)
         s_b, f_b = m2.trajectories_safe(P[None], 1.0, 0.6)
         assert (ok, first) == (bool(s_b[0]), int(f_b[0]))
+
+
+def check_random_scenes(ops, n_scenes=12, n_rays=150, seed=0):
+    """Random maps against the oracle's dict walk, bit for bit: non-dyadic resolutions (0.1 .. 0.9 m), 3-D rays from
+    random origins incl. axis-aligned and diagonal ones, hit distances from 0 to beyond the range, two scans per
+    scene; then random point queries and trajectory checks on the result."""
+    rng = np.random.default_rng(seed)
+    for sc in range(n_scenes):
+        res = float(rng.choice([0.1, 0.17, 0.2, 0.3, 0.37, 0.5, 0.9]))
+        max_range = float(rng.uniform(4.0, 15.0))
+        m = ExplicitGeometricMapper(resolution=res, max_range=max_range, capacity=64, ops=ops)
+        o = mo.VoxelMap(res, max_range)
+        for _ in range(int(rng.integers(0, 3))):
+            c, r = rng.uniform(-4, 4, 3), float(rng.uniform(0.2, 1.0))
+            m.add_obstacle(c, r); o.add_obstacle(c, r)
+        for scan in range(2):
+            origin = rng.uniform(-3, 3, 3)
+            dirs = rng.normal(size=(n_rays, 3))
+            special = np.array([[1, 0, 0], [0, -1, 0], [0, 0, 1], [1, 1, 0], [1, -1, 1], [-1, -1, -1]], float)
+            dirs[:len(special)] = special
+            hits = np.where(rng.random(n_rays) < 0.5, rng.uniform(0.0, 1.5 * max_range, n_rays), np.nan)
+            hits[:2] = [0.0, np.nan]
+            obs = [SensorObservation(position=origin.copy(), direction=d, hit_distance=(None if np.isnan(h) else float(h)),
+                                     max_range=max_range * 1.2, timestamp=0.0) for d, h in zip(dirs, hits)]
+            res_dev = m.update_map(obs)
+            n_or = o.update_map([origin] * n_rays, dirs, [None if np.isnan(h) else float(h) for h in hits], [max_range * 1.2] * n_rays)
+            assert res_dev["updated_voxels"] == n_or and res_dev["total_voxels"] == len(o.voxels), (sc, scan)
+        for a, b in zip(m.map.items(), o.items()):
+            assert np.array_equal(a, b), (sc, res)
+        q = rng.uniform(-12, 12, (500, 3))
+        assert np.array_equal(m.query_occupancy_batch(q), o.query(q))
+        P = rng.uniform(-6, 6, (16, 12, 3))
+        safe, first = m.trajectories_safe(P, 0.7, 0.6)
+        exp = [o.is_trajectory_safe(p, 0.7, 0.6) for p in P]
+        assert np.array_equal(safe, [e[0] for e in exp]) and np.array_equal(first, [e[1] for e in exp])
