@@ -221,7 +221,7 @@ __device__ __forceinline__ double grid_axis_value(const GridDev& g, int a, int i
   return t + g.start[a];
 }
 
-constexpr int kGridRun = 1024;   // consecutive cells owned by one wavefront (16 rows of 64)
+constexpr int kGridRun = 256;    // consecutive cells owned by one wavefront (4 rows of 64: enough wavefronts to hide the probe latency)
 
 // Axis tables in LDS: voxel index of every linspace point, per axis -- 3n divisions per workgroup instead of 3 per cell.
 __device__ __forceinline__ void grid_stage_axes(const VoxDev& d, const GridDev& g, int* ax) {
@@ -262,23 +262,40 @@ voxel_grid_count_kernel(VoxDev d, GridDev g, int32_t* __restrict__ run_counts, u
   if (lane == 0) run_counts[run] = cnt;
 }
 
+// Exclusive prefix sum of the per-run counts (one workgroup; offsets[nruns] = total): every thread sums a contiguous
+// chunk, the 1024 chunk sums are scanned with wave shuffles + the 16 wave totals in LDS, then the chunk is rewritten.
+__global__ void __launch_bounds__(1024)
+voxel_grid_scan_kernel(const int32_t* __restrict__ counts, int nruns, int32_t* __restrict__ offsets) {
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int chunk = (nruns + 1023) / 1024;
+  const int lo = tid * chunk, hi = (lo + chunk < nruns) ? lo + chunk : nruns;
+  int sum = 0;
+  for (int i = lo; i < hi; ++i) sum += counts[i];
+  int incl = sum;                                            // inclusive scan across the wavefront
+  for (int off = 1; off < kWave; off <<= 1) {
+    const int up = __shfl(incl, lane - off >= 0 ? lane - off : lane, kWave);
+    if (lane >= off) incl += up;
+  }
+  if (lane == kWave - 1) wave_tot[wave] = incl;
+  __syncthreads();
+  int base = 0, total = 0;
+  for (int w = 0; w < 16; ++w) { if (w < wave) base += wave_tot[w]; total += wave_tot[w]; }
+  int run = base + incl - sum;
+  for (int i = lo; i < hi; ++i) { offsets[i] = run; run += counts[i]; }
+  if (tid == 0) offsets[nruns] = total;
+}
+
 template <typename R>
 __global__ void __launch_bounds__(256)
-voxel_grid_select_kernel(GridDev g, const int32_t* __restrict__ run_counts, const unsigned long long* __restrict__ masks,
+voxel_grid_select_kernel(GridDev g, const int32_t* __restrict__ offsets, const unsigned long long* __restrict__ masks,
                          int nruns, R* __restrict__ spheres, int32_t* __restrict__ count) {
   const int lane = lane_id();
   const long long run = (long long)blockIdx.x * (blockDim.x / kWave) + (threadIdx.x / kWave);
   const long long base = run * kGridRun;
   if (base >= g.M) return;
-  // rank of this run's first occupied cell and the grand total, from the per-run counts of the first pass
-  int before = 0, total = 0;
-  for (int j = lane; j < nruns; j += kWave) {
-    const int c = run_counts[j];
-    total += c;
-    if (j < run) before += c;
-  }
-  before = wave_sum_i32(before);
-  total = wave_sum_i32(total);
+  // rank of this run's first occupied cell and the grand total, from the scanned per-run counts
+  const int before = offsets[run], total = offsets[nruns];
   const int step = (g.target > 0 && total / g.target > 1) ? total / g.target : 1;   // max(1, n_occupied // target)
   int rank = before;
   const long long n = g.n;
@@ -521,12 +538,16 @@ int voxel_local_spheres_impl(const se3mpc_voxel_map* m, const double* centre, do
   const int nruns = grid_runs(g.M);
   const int nblk = grid_for(nruns, 4);
   const size_t lds = (size_t)3 * g.n * sizeof(int);
-  // workspace: [nruns run counts | pad to 8 B | nruns * 16 occupancy masks (one 64-bit ballot per 64 cells)]
-  unsigned long long* masks = reinterpret_cast<unsigned long long*>(workspace + ((nruns + 1) & ~1));
+  // workspace: [nruns run counts | nruns + 1 offsets | pad to 8 B | one 64-bit occupancy ballot per 64 cells]
+  int32_t* offsets = workspace + nruns;
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>(workspace + ((2 * nruns + 2) & ~1));
   hipLaunchKernelGGL(voxel_grid_count_kernel, dim3(nblk), dim3(256), lds, s, d, g, workspace, masks);
   rc = launch_status("se3mpc_voxel_local_spheres(count)");
   if (rc) return rc;
-  hipLaunchKernelGGL(voxel_grid_select_kernel<R>, dim3(nblk), dim3(256), 0, s, g, workspace, masks, nruns, spheres, count);
+  hipLaunchKernelGGL(voxel_grid_scan_kernel, dim3(1), dim3(1024), 0, s, workspace, nruns, offsets);
+  rc = launch_status("se3mpc_voxel_local_spheres(scan)");
+  if (rc) return rc;
+  hipLaunchKernelGGL(voxel_grid_select_kernel<R>, dim3(nblk), dim3(256), 0, s, g, offsets, masks, nruns, spheres, count);
   return launch_status("se3mpc_voxel_local_spheres(select)");
 }
 
@@ -627,7 +648,7 @@ extern "C" int se3mpc_voxel_local_workspace(int cells_per_axis) {
   if (cells_per_axis < 1) return 1;
   const long long n = cells_per_axis;
   const int nruns = grid_runs(n * n * n);
-  return ((nruns + 1) & ~1) + 2 * nruns * (kGridRun / kWave);            // run counts + one 64-bit mask per 64 cells
+  return ((2 * nruns + 2) & ~1) + 2 * nruns * (kGridRun / kWave);        // run counts, offsets, one 64-bit mask per 64 cells
 }
 
 #define SE3MPC_DEFINE_VOXEL_API(SUF, R)                                                                                    \
