@@ -362,6 +362,95 @@ class SE3MPCPlanner(BasePlanner):
         _, cmin, viol = ops.obstacle_residual(self._params(horizon=N), X, sph, materialize=False)
         return dict(min_residual=float(cmin[0]), violation=float(viol[0]))
 
+    # ------------------------------------------------------------------ planner.py:329-654: the path's own functions
+    # Same names and arguments as the reference's private methods; each is one call into the lane-layout kernel that
+    # replaces it (one trajectory = one lane), float64, host arrays in and out.  The solver does not go through these
+    # (it has them fused in one launch); they are here for callers and tests that use the reference's method names.
+    def _lane1(self, x):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(to_float(x), float).reshape(-1, 1))).to(self._get_ops().be.device)
+
+    def _pack_variables(self, positions, velocities, thrust_vectors) -> np.ndarray:              # :361-367
+        return np.concatenate([np.asarray(positions).flatten(), np.asarray(velocities).flatten(), np.asarray(thrust_vectors).flatten()])
+
+    def _unpack_variables(self, x, N: int):                                                         # :369-376
+        x = np.asarray(x)
+        return x[:N * 3].reshape(N, 3), x[N * 3:2 * N * 3].reshape(N, 3), x[2 * N * 3:3 * N * 3].reshape(N, 3)
+
+    def _create_straight_line_initialization(self, current_state: DroneState, N: int) -> np.ndarray:   # :329-359
+        ops = self._get_ops()
+        goal = self.goal_position if self.goal_position is not None else np.zeros(3)
+        X0 = ops.init(self._params(horizon=N), self._lane1(current_state.position), self._lane1(current_state.velocity), self._lane1(goal))
+        return ops.be.to_host(X0)[:, 0].astype(float)
+
+    def _initialize_optimization_variables(self, current_state: DroneState, N: int) -> np.ndarray:     # :282-292
+        if self.warm_start_enabled and self.last_solution is not None:
+            return self._create_warm_start(current_state, N)
+        return self._create_straight_line_initialization(current_state, N)
+
+    def _setup_optimization_bounds(self, N: int) -> List[Tuple[float, float]]:                      # :378-402
+        c = self.se3_config
+        txy = c.max_thrust * np.sin(c.max_tilt_angle)
+        return ([(-100.0, 100.0)] * (3 * N) + [(-c.max_velocity, c.max_velocity)] * (3 * N)
+                + [(-txy, txy), (-txy, txy), (c.min_thrust, c.max_thrust)] * N)
+
+    def _setup_optimization_constraints(self, current_state: DroneState, N: int) -> List[Dict]:       # :404-424
+        cons = [{"type": "eq", "fun": lambda x: self._dynamics_constraints(x, current_state, N)}]
+        if self.obstacles:
+            cons.append({"type": "ineq", "fun": lambda x: self._obstacle_constraints(x, N)})
+        return cons
+
+    def _dynamics_constraints(self, x, current_state: DroneState, N: int) -> np.ndarray:             # :426-462
+        ops = self._get_ops()
+        R = ops.dynamics_residual(self._params(horizon=N), self._lane1(x), self._lane1(current_state.position),
+                                  self._lane1(current_state.velocity))
+        return ops.be.to_host(R)[:, 0].astype(float)
+
+    def _dynamics_constraints_jacobian(self, x, current_state: DroneState, N: int):                   # :464-470
+        return None
+
+    def _physical_constraints(self, x, N: int) -> np.ndarray:                                        # :472-497
+        ops = self._get_ops()
+        return ops.be.to_host(ops.physical_constraints(self._params(horizon=N), self._lane1(x)))[:, 0].astype(float)
+
+    def _obstacle_constraints(self, x, N: int) -> np.ndarray:                                        # :499-514
+        import torch
+        if not self.obstacles:
+            return np.array([])
+        ops = self._get_ops()
+        sph = torch.tensor([[*c, r] for c, r in self.obstacles], dtype=torch.float64, device=ops.be.device)
+        C, _, _ = ops.obstacle_residual(self._params(horizon=N), self._lane1(x), sph, materialize=True)
+        return ops.be.to_host(C)[:, 0].astype(float)
+
+    def _objective_function(self, x) -> float:                                                       # :516-550
+        ops = self._get_ops()
+        N = self.se3_config.prediction_horizon
+        goal = None if self.goal_position is None else self._lane1(self.goal_position)
+        f, _ = ops.cost_grad(self._params(horizon=N), self._lane1(x), goal, want_grad=False)
+        return float(ops.be.to_host(f)[0])
+
+    def _objective_gradient(self, x) -> np.ndarray:                                                  # :552-580
+        ops = self._get_ops()
+        N = self.se3_config.prediction_horizon
+        goal = None if self.goal_position is None else self._lane1(self.goal_position)
+        _, g = ops.cost_grad(self._params(horizon=N), self._lane1(x), goal)
+        return ops.be.to_host(g)[:, 0].astype(float)
+
+    def _compute_attitudes_and_rates(self, thrust_vectors, velocities=None):                          # :604-654
+        ops = self._get_ops()
+        T = np.asarray(to_float(thrust_vectors), float)
+        N = len(T)
+        _, att, rates, _ = ops.extract(self._params(horizon=N), self._lane1(T))
+        return ops.be.to_host(att)[:, 0].reshape(N, 3).astype(float), ops.be.to_host(rates)[:, 0].reshape(N, 3).astype(float)
+
+    def _extract_solution_from_result(self, x, N: int) -> Dict[str, np.ndarray]:                     # :582-602
+        ops = self._get_ops()
+        P, V, T = self._unpack_variables(np.asarray(x, float), N)
+        acc, att, rates, thr = ops.extract(self._params(horizon=N), self._lane1(T))
+        h = lambda a, shape: ops.be.to_host(a)[:, 0].reshape(shape).astype(float)
+        return {"positions": P, "velocities": V, "thrust_vectors": T, "accelerations": h(acc, (N, 3)), "attitudes": h(att, (N, 3)),
+                "body_rates": h(rates, (N, 3)), "thrusts": h(thr, (N,))}
+
     # ------------------------------------------------------------------ planner.py:656-757
     def _create_trajectory_from_solution(self, solution: Dict[str, np.ndarray], start_time: float) -> Trajectory:
         N = len(solution["positions"])

@@ -251,3 +251,38 @@ def case_sitl_unit_planner(r: Rig):
 
 
 OTHER_REFERENCE_CASES = [case_se3_mpc_speed, case_planner_controller_integration, case_sitl_unit_planner]
+
+
+def case_private_path_methods(r: Rig, data, meta, tol=1e-9):
+    """The reference's private path methods on the mirror class (same names and arguments, each one lane-layout kernel
+    call) against what the reference's own methods returned for the same arguments (tests/golden/path_functions.npz)."""
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCPlanner
+    close = lambda a, b, what: np.testing.assert_allclose(np.asarray(a, float), np.asarray(b, float), rtol=tol, atol=tol * 10, err_msg=what)
+    for c in meta["cases"]:
+        if abs(c["dt"] - 1 / 400) > 1e-12:
+            continue                                   # the class forces the timing manager's dt (planner.py:99-105)
+        k, N = c["key"], c["N"]
+        pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N))
+        pl._ops = r.planner._get_ops()
+        if c["with_goal"]:
+            pl.set_goal(data[k + "goal"])
+        for cc, rr in zip(data[k + "obs_c"], data[k + "obs_r"]):
+            pl.add_obstacle(cc, float(rr))
+        close(np.array(pl._setup_optimization_bounds(N)), data[k + "bounds"], k + "bounds")
+        p0s, v0s = np.atleast_2d(data[k + "p0"]), np.atleast_2d(data[k + "v0"])
+        x0i = np.atleast_2d(data[k + "x0_init"])
+        for j, (X1, Xe1) in enumerate(zip(data[k + "X"], data[k + "Xe"])):
+            st = DroneState(timestamp=0.0, position=p0s[min(j, len(p0s) - 1)], velocity=v0s[min(j, len(v0s) - 1)])
+            close(pl._objective_function(X1), data[k + "f"][j], k + "f")
+            close(pl._objective_gradient(X1), data[k + "g"][j], k + "g")
+            close(pl._dynamics_constraints(X1, st, N), data[k + "dyn"][j], k + "dyn")
+            close(pl._physical_constraints(X1, N), data[k + "phys"][j], k + "phys")
+            close(pl._obstacle_constraints(X1, N), data[k + "obs"][j], k + "obs")
+            close(pl._create_straight_line_initialization(st, N), x0i[min(j, len(x0i) - 1)], k + "x0")
+            ex = pl._extract_solution_from_result(Xe1, N)
+            for name in ("accelerations", "attitudes", "body_rates", "thrusts"):
+                close(ex[name], data[k + "ex_" + name][j], k + name)
+            P, V, T = pl._unpack_variables(Xe1, N)
+            assert np.array_equal(pl._pack_variables(P, V, T), Xe1)
+            att, rates = pl._compute_attitudes_and_rates(T, V)
+            close(att, ex["attitudes"], k + "att"); close(rates, ex["body_rates"], k + "rates")

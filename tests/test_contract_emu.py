@@ -42,6 +42,10 @@ def test_other_reference_planner_tests(attach, case):
         case(rig)
 
 
+def test_private_path_methods_match_reference(attach, golden_path):
+    cc.case_private_path_methods(cc.Rig(attach), *golden_path)
+
+
 def test_receding_horizon_warm_start(attach):
     cc.case_receding_horizon_warm_start(cc.Rig(attach))
 

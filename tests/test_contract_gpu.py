@@ -37,3 +37,7 @@ def test_other_reference_planner_tests(case):
     if case is cc.case_se3_mpc_speed:
         print(f"100 plans: mean {out[0]:.3f} ms, max {out[1]:.3f} ms")
         assert out[0] <= 1.0                                   # the MI355X path: two orders under the reference's 50 ms budget
+
+
+def test_private_path_methods_match_reference(golden_path):
+    cc.case_private_path_methods(cc.Rig(), *golden_path)
