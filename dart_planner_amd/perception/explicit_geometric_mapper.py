@@ -161,6 +161,28 @@ class ExplicitGeometricMapper:
         self.total_queries += n ** 3
         return np.array(self.map.be.to_host(spheres)[:k], dtype=float)
 
+    # ------------------------------------------------------------------ mapper.py:314-353 (helpers of the reference's API)
+    def _bayesian_update(self, voxel: VoxelData, hit: bool) -> None:
+        """One update of a HOST snapshot entry with the reference's expression (the map itself is updated on the
+        device by update_map; this exists for callers of the reference's helper)."""
+        p = voxel.occupancy_probability
+        like = self.prob_hit if hit else 1 - self.prob_miss
+        num = like * p
+        den = like * p + (1 - like) * (1 - p)
+        if den > 0:
+            voxel.occupancy_probability = num / den
+        voxel.occupancy_probability = float(np.clip(voxel.occupancy_probability, 0.01, 0.99))
+
+    def _get_safety_margin_positions(self, center, margin: float) -> List[np.ndarray]:
+        center = np.asarray(to_float(center), float)
+        out = [center]
+        for axis in range(3):
+            for sgn in (-1, 1):
+                off = np.zeros(3)
+                off[axis] = sgn * margin
+                out.append(center + off)
+        return out
+
     # ------------------------------------------------------------------ mapper.py:355-366
     def get_mapping_stats(self) -> Dict[str, Any]:
         nv = len(self.map)

@@ -137,6 +137,13 @@ def check_edges(ops):
     assert len(keys) == len(ijk) == len(m.map) and m.map.capacity * 85 >= 100 * len(ijk)
     order = np.lexsort((ijk[:, 2], ijk[:, 1], ijk[:, 0]))
     assert np.array_equal(keys, ijk[order]) and np.array_equal(prob, np.linspace(0.0, 1.0, len(ijk))[order])
+    # helpers of the reference's API
+    from dart_planner_amd.perception.explicit_geometric_mapper import VoxelData
+    v = VoxelData()
+    m._bayesian_update(v, hit=False)
+    assert v.occupancy_probability == mo.VoxelMap.bayes(0.5, False)
+    pts = m._get_safety_margin_positions(np.array([1.0, 2.0, 3.0]), 0.5)
+    assert len(pts) == 7 and np.array_equal(pts[1], [0.5, 2.0, 3.0]) and np.array_equal(pts[6], [1.0, 2.0, 3.5])
     # C-ABI statuses
     lib = ops.lib
     assert lib.voxel_status("clear", None, 0) == -1                                           # SE3MPC_ERR_NULL
