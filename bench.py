@@ -119,10 +119,20 @@ def cpu_baseline(B, N, seconds):
         orc.objective_loops(x, goal, cfg); orc.gradient_loops(x, goal, cfg)
         m += 1
     el1 = time.perf_counter() - t1
+    # the reference-shaped SOLVE (plan_trajectory's arithmetic: per-step Python loops in f and g, SciPy L-BFGS-B), one
+    # problem per call, one core: what the p95 solve latency of the `solve` leg stands beside (~5 ms at N=30)
+    ts = []
+    for i in range(40):
+        gi = rng.uniform(-5, 5, 3); gi[2] = abs(gi[2]) + 0.5
+        t2 = time.perf_counter()
+        orc.plan_reference_shaped(np.array([0.0, 0.0, 1.0]), np.zeros(3), gi, cfg)
+        ts.append((time.perf_counter() - t2) * 1e3)
     return dict(value=total, unit="rollouts/s", cores=cores, kind="port",
                 sample=f"{cores} worker processes x {seconds:.0f} s of the oracle's batched NumPy rollout+cost+grad (float64), "
                        f"{Bs} trajectories per pass, horizon {N} ({sum(n for n, _ in res)} passes in all)",
-                single_core_value=single[0] * Bs / single[1], reference_shaped_evals_per_s=m / el1, host_cpus=os.cpu_count())
+                single_core_value=single[0] * Bs / single[1], reference_shaped_evals_per_s=m / el1,
+                reference_shaped_solve_ms=dict(horizon=N, calls=len(ts), p50=float(np.percentile(ts, 50)), p95=float(np.percentile(ts, 95))),
+                host_cpus=os.cpu_count())
 
 
 def timed_region(torch, dist, world, dev, K, launch_all, graph, keys, allreduce_min_keys):
