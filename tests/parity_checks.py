@@ -291,10 +291,12 @@ def check_solver_vs_oracle(h: Harness, N: int, B: int, seed: int = 11, **overrid
 
 
 # --------------------------------------------------------------------------------------- f-2
-def check_spheres_from_grid(h: Harness, data, meta):
+def check_spheres_from_grid(h: Harness, data, meta, only=None):
     """Occupancy grid (produced by the reference's mapper) -> sphere table, against the reference's selection."""
     for c in meta["cases"]:
         k = c["key"]
+        if only is not None and k not in only:
+            continue
         grid, occ, exp = data[k + "grid"], data[k + "occ"], data[k + "spheres"]
         assert np.allclose(orc.local_grid_positions(c["centre"], c["size"], c["resolution"]), grid, rtol=0, atol=1e-12), k
         assert np.array_equal(orc.spheres_from_grid(grid, occ, target=c["target"]), exp), k

@@ -63,7 +63,8 @@ def test_solver_extraction_and_cold_start(emu_ops):
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_spheres_from_grid(emu_ops, golden_mapper, dt):
-    pc.check_spheres_from_grid(harness(emu_ops, dt), *golden_mapper)
+    # (float32 under emulation: two of the four golden grids; the GPU suite sweeps all four in both types)
+    pc.check_spheres_from_grid(harness(emu_ops, dt), *golden_mapper, only=None if dt == np.float64 else {"m_sparse_", "m_test_file_divisor_"})
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
