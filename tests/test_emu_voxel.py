@@ -29,7 +29,7 @@ def golden_map():
     return (np.load(os.path.join(HERE, "golden", "mapper_map.npz")), json.load(open(os.path.join(HERE, "golden", "mapper_map.json"))))
 
 
-@pytest.mark.parametrize("scene", [0, 1, 2])
+@pytest.mark.parametrize("scene", [0, 2])          # scene 1 (456 rays at 0.2 m, ~3e5 emulated lanes per launch) runs in the GPU suite only
 def test_scene_matches_reference_mapper(emu_ops, golden_map, scene):
     data, meta = golden_map
     # (the array form of update_map is re-checked on the edge-case scene here and on all three on the GPU)
