@@ -13,12 +13,21 @@ RCCL all-reduce(MIN) of the K packed (cost, index) keys at the end of the timed 
 (SURVEY.md section 8e).  Steps cycle through a ring of distinct input/output batches larger than the
 256 MiB Infinity Cache, so every step streams its operands from HBM.
 
-Two legs time the same K steps (SURVEY.md section 7 "report both"):
+Two legs time the same steps (SURVEY.md section 7 "report both"):
   * primary (`value`, `roofline`): the steps are independent batches (a Monte-Carlo sweep, many
     planners), so `--steps-per-launch` S = 64 of them go into ONE multi-batch kernel launch (grid.y);
   * `single_launch`: one kernel launch per 8192-rollout step (sequentially dependent sampling
     iterations of one planner): 6 MB per launch = 1 us of HBM time, i.e. latency-bound.
 Launches are captured once into a hipGraph and replayed inside the timed region.
+
+The launch shape never depends on `--steps`: a *pass* is ceil(K / S) full S-batch launches, and the pass is
+repeated (`repeats`) until the timed region lasts at least `--min-ms` (20 ms), so a driver that asks for
+K = 20 steps measures the same steady state as K = 20000; `steps` echoes K, `steps_timed` is what ran,
+`ms_per_step` is the mean over the steps that ran.
+
+`--gpus N` with N > 1 and no torchrun environment: bench.py starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, as a child process and BEFORE
+any HIP call, relays rank 0's JSON line and exits non-zero unless N ranks joined.
 """
 import argparse
 import json
@@ -39,7 +48,7 @@ HBM_PEAK_GBPS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E peak 8.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--steps", type=int, default=20480)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--batch", type=int, default=8192, help="rollouts per GPU per step (BASELINE.json metric: 8192)")
     ap.add_argument("--horizon", type=int, default=30)
@@ -54,6 +63,13 @@ def parse():
     ap.add_argument("--no-single", action="store_true", help="skip the one-launch-per-step leg")
     ap.add_argument("--variant", type=int, default=0, help="se3mpc_set_rollout_variant (0 = auto)")
     ap.add_argument("--sweep", action="store_true", help="also time saturating batch sizes (extra keys)")
+    ap.add_argument("--min-ms", type=float, default=20.0, help="the pass of ceil(K/S) launches is repeated until the timed region lasts this long")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank plumbing only, no HIP: spawn / rendezvous (gloo) / key all-reduce / JSON line with value null "
+                         "(what the CPU test-suite runs to check that --gpus N really starts N ranks)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config-2 / config-3 legs")
+    ap.add_argument("--no-iterated", action="store_true", help="skip the on-device K-iteration leg")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop Monte-Carlo leg")
     return ap.parse_args()
 
 
@@ -135,23 +151,24 @@ def cpu_baseline(B, N, seconds):
                 host_cpus=os.cpu_count())
 
 
-def timed_region(torch, dist, world, dev, K, launch_all, graph, keys, allreduce_min_keys):
-    """The contract's timed region: barrier + synchronize, K steps, [one bucketed all-reduce(MIN) of the
-    K keys], synchronize + barrier; MAX over ranks.  Returns (elapsed_s, device_ms between the HIP events
-    that bracket the K steps on the launch stream)."""
+def timed_region(torch, dist, world, dev, replays, graph, launch_all, keys, allreduce_min_keys):
+    """The contract's timed region: barrier + synchronize, `replays` x (the captured passes), [one bucketed
+    all-reduce(MIN) of the step keys], synchronize + barrier; MAX over ranks.  Returns (elapsed_s, device_ms
+    between the HIP events that bracket the launches on the launch stream)."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     e0.record()
-    if graph is not None:
-        graph.replay()
-    else:
-        launch_all()
+    for _ in range(replays):
+        if graph is not None:
+            graph.replay()
+        else:
+            launch_all()
     e1.record()
     if world > 1:
-        allreduce_min_keys(keys)     # the single exchange: ONE bucketed all-reduce(MIN) of the K packed keys
+        allreduce_min_keys(keys)     # the single exchange: ONE bucketed all-reduce(MIN) of the packed step keys
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -177,13 +194,111 @@ def capture(torch, dev, fn):
     return graph
 
 
+def device_ms(torch, fn, reps):
+    """Mean device time of fn() over `reps` back-to-back calls (HIP events on the launch stream)."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+MAX_GRAPH_NODES = 2048
+
+
+def timed_plan(K, per_launch, pass_ms, min_ms):
+    """How the timed region is built so that its launch shape never depends on K: a pass = ceil(K / per_launch)
+    FULL launches; `passes_per_graph` passes are captured into one hipGraph (at most MAX_GRAPH_NODES kernel
+    nodes), which is replayed `replays` times; passes x pass_ms >= min_ms."""
+    launches_per_pass = max(1, math.ceil(K / per_launch))
+    passes = max(1, math.ceil(min_ms / max(pass_ms, 1e-6)))
+    per_graph = max(1, min(passes, MAX_GRAPH_NODES // launches_per_pass))
+    replays = math.ceil(passes / per_graph)
+    return dict(launches_per_pass=launches_per_pass, steps_per_pass=launches_per_pass * per_launch,
+                passes_per_graph=per_graph, replays=replays, repeats=per_graph * replays)
+
+
+def spawn_ranks(a):
+    """`--gpus N` without a torchrun environment: start N ranks as a CHILD process (never exec: this process may
+    not touch the GPU before, and does not), relay the JSON line, fail loudly when fewer than N ranks joined."""
+    import socket
+    import subprocess
+    import torch
+    backend = "gloo" if a.dry_run else os.environ.get("SE3MPC_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()                  # counting devices does not initialise HIP
+    if backend == "nccl" and ndev < a.gpus:
+        print(f"[bench] --gpus {a.gpus} but only {ndev} GPU(s) are visible: refusing to report a {a.gpus}-GPU line",
+              file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print(f"[bench] the {a.gpus}-rank child failed (rc={proc.returncode})", file=sys.stderr)
+        return proc.returncode or 1
+    got = json.loads(line)
+    if got.get("n_gpus") != a.gpus or got.get("ranks_joined") != a.gpus:
+        print(f"[bench] asked for {a.gpus} ranks, the line reports n_gpus={got.get('n_gpus')} ranks_joined={got.get('ranks_joined')}",
+              file=sys.stderr)
+        return 3
+    print(line, flush=True)
+    return 0
+
+
+def dry_run(a, rank, world):
+    """Everything around the kernels, without HIP: the ranks rendezvous over gloo, count themselves, all-reduce(MIN) one
+    synthetic packed key per step exactly as the timed region does, and rank 0 prints a line with value = null."""
+    import torch
+    import torch.distributed as dist
+    from dart_planner_amd.distributed import allreduce_min_keys, init_distributed
+    init_distributed("gloo")
+    joined = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64)
+        dist.all_reduce(one)
+        joined = int(one.item())
+    B, K = a.batch, max(1, a.steps)
+    # rank r "finds" cost r + 1 at its first trajectory: the all-reduced key must name rank 0's trajectory 0
+    keys = torch.full((K,), ((rank + 1) << 32) | (rank * B), dtype=torch.int64)
+    allreduce_min_keys(keys)
+    ok = bool((keys == ((1 << 32) | 0)).all())
+    if rank == 0:
+        print(json.dumps({"metric": "SE(3) rollouts/sec (N=30, batch=8192) + p95 solve ms, at 1/2/4/8 MI355X", "value": None,
+                          "unit": "rollouts/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "dry_run": True,
+                          "ranks_joined": joined, "dist_backend": "gloo" if world > 1 else None, "keys_valid": ok}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        raise SystemExit(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: the two must agree")
+    if a.dry_run:
+        return dry_run(a, rank, world)
     cpu_stats = None
     if world == 1 and not a.no_cpu_baseline:
         cpu_stats = cpu_baseline(a.batch, a.horizon, a.cpu_seconds)      # before any HIP call: it spawns worker processes
@@ -194,9 +309,13 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from dart_planner_amd.distributed import allreduce_min_keys, init_distributed
-    init_distributed(os.environ.get("SE3MPC_DIST_BACKEND", "nccl"), device=dev)
-    if a.gpus != world and rank == 0:
-        print(f"[bench] --gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1", file=sys.stderr)
+    backend = os.environ.get("SE3MPC_DIST_BACKEND", "nccl")
+    init_distributed(backend, device=dev)
+    joined = 1
+    if world > 1:
+        one = torch.ones(1, dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(one)
+        joined = int(one.item())
 
     from dart_planner_amd.capi import Params
     from dart_planner_amd.ops import Ops, TorchBackend
@@ -210,37 +329,51 @@ def main():
     ring = S * max(2, math.ceil(ring / S))                     # whole launches, consecutive launches on disjoint slots
     p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=3 + rank)
     per = (B + 63) // 64                                        # wave-key slots per batch
-    wave_keys = torch.zeros(max(K, W, S), per, dtype=torch.int64, device=dev)
-    keys = torch.full((max(K, 1),), -1, dtype=torch.int64, device=dev)
     base = rank * B
+    state = {}
 
     def launch(i0, n):
         """steps i0 .. i0+n-1 (n <= S consecutive ring slots) as ONE launch; step i's wavefronts write
         their partial argmin keys to wave_keys[i]"""
         s0 = i0 % ring
+        wk = state["wave_keys"]
         if n == 1:
-            ops.rollout_cost_grad(prm, p0[s0], v0[s0], goal[s0], T[s0], out=(cost[s0], grad[s0]), wave_keys=wave_keys[i0], index_base=base)
+            ops.rollout_cost_grad(prm, p0[s0], v0[s0], goal[s0], T[s0], out=(cost[s0], grad[s0]), wave_keys=wk[i0], index_base=base)
         else:
             ops.rollout_cost_grad_batched(prm, p0[s0:s0 + n], v0[s0:s0 + n], goal[s0:s0 + n], T[s0:s0 + n], cost[s0:s0 + n],
-                                          grad[s0:s0 + n], wave_keys=wave_keys[i0:i0 + n], index_base=base)
+                                          grad[s0:s0 + n], wave_keys=wk[i0:i0 + n], index_base=base)
 
     def run_steps(nsteps, per_launch, fold=True):
-        i = 0
-        while i < nsteps:
-            n = min(per_launch, nsteps - i)
-            n = min(n, ring - (i % ring))
-            launch(i, n)
-            i += n
+        """nsteps (a multiple of per_launch) steps as FULL launches of per_launch consecutive ring slots"""
+        assert nsteps % per_launch == 0 and ring % per_launch == 0
+        for i in range(0, nsteps, per_launch):
+            launch(i, per_launch)
         if fold:                                                # one bucketed fold of all steps' wave keys -> keys[step]
-            ops.reduce_keys(wave_keys[:nsteps], keys[:nsteps])
+            ops.reduce_keys(state["wave_keys"][:nsteps], state["keys"][:nsteps])
 
     results = {}
     for mode, per_l in (("primary", S), ("single_launch", 1)):
         if mode == "single_launch" and (S == 1 or a.no_single):
             continue
-        run_steps(W, per_l, fold=False)                         # untimed warm-up (eager)
+        # calibration: device time of one pass (also the untimed warm-up: W steps rounded up to whole launches)
+        lpp = max(1, math.ceil(K / per_l))
+        state["wave_keys"] = torch.zeros(max(lpp, math.ceil(W / per_l)) * per_l, per, dtype=torch.int64, device=dev)
+        state["keys"] = torch.full((state["wave_keys"].shape[0],), -1, dtype=torch.int64, device=dev)
+        run_steps(math.ceil(max(W, 1) / per_l) * per_l, per_l, fold=False)
         torch.cuda.synchronize()
-        graph = None if a.no_graph else capture(torch, dev, lambda: run_steps(K, per_l))
+        cal = capture(torch, dev, lambda: run_steps(lpp * per_l, per_l, fold=False))
+        pass_ms = device_ms(torch, cal.replay, 3)
+        del cal
+        if world > 1:                                           # every rank must build the same plan
+            pm = torch.tensor([pass_ms], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(pm, op=dist.ReduceOp.MAX)
+            pass_ms = float(pm.item())
+        plan = timed_plan(K, per_l, pass_ms, a.min_ms)
+        nsteps_graph = plan["passes_per_graph"] * plan["steps_per_pass"]
+        state["wave_keys"] = torch.zeros(nsteps_graph, per, dtype=torch.int64, device=dev)
+        state["keys"] = keys = torch.full((nsteps_graph,), -1, dtype=torch.int64, device=dev)
+        body = lambda: run_steps(nsteps_graph, per_l)
+        graph = None if a.no_graph else capture(torch, dev, body)
         if world > 1:
             # untimed: the first collective of a given shape pays communicator / kernel set-up (ms); the timed
             # region must only see the steady-state exchange
@@ -248,36 +381,50 @@ def main():
             dist.all_reduce(torch.zeros(1, dtype=torch.float64, device=dev), op=dist.ReduceOp.MAX)
         keys.fill_(-1)
         torch.cuda.synchronize()
-        elapsed, dev_ms = timed_region(torch, dist, world, dev, K, lambda: run_steps(K, per_l), graph, keys, allreduce_min_keys)
-        nlaunch = sum(1 for _ in _launch_sizes(K, per_l, ring))
-        kh = keys[:K].cpu().numpy().view(np.uint64)
+        elapsed, dev_ms = timed_region(torch, dist, world, dev, plan["replays"], graph, body, keys, allreduce_min_keys)
+        nlaunch = plan["repeats"] * plan["launches_per_pass"]
+        kh = keys.cpu().numpy().view(np.uint64)
         results[mode] = dict(elapsed=elapsed, launch_ms=dev_ms / nlaunch, nlaunch=nlaunch, per=per_l, graph=graph is not None,
+                             steps_timed=plan["repeats"] * plan["steps_per_pass"], plan=plan, device_ms=dev_ms,
                              keys_valid=bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B))))
         del graph
+    del state["wave_keys"], state["keys"]
 
     solve_stats = None if a.no_solve else solve_leg(torch, ops, dev, B, N, rank, world)
     voxel_stats = None if (a.no_obstacle_source or rank != 0) else obstacle_source_leg(torch, ops, dev)
+    del p0, v0, goal, T, cost, grad
+    torch.cuda.empty_cache()
+    config_stats = None if (a.no_configs or rank != 0) else config_legs(torch, ops, dev, a.min_ms)
+    iter_stats = None if (a.no_iterated or rank != 0) else iterated_leg(torch, ops, dev, B, N, a.min_ms)
+    loop_stats = None if (a.no_closed_loop or rank != 0) else closed_loop_leg(torch, ops, dev)
 
     if rank == 0:
         r = results["primary"]
-        per_launch_rollouts = B * min(S, K)
+        per_launch_rollouts = B * S
         achieved = bytes_per_rollout * per_launch_rollouts / (r["launch_ms"] * 1e-3) / 1e9
-        traffic = profiled_traffic(B, N, S)
+        traffic = profiled_traffic(B, N)
+        value = world * B * r["steps_timed"] / r["elapsed"]
         res = {
             "metric": "SE(3) rollouts/sec (N=30, batch=8192) + p95 solve ms, at 1/2/4/8 MI355X",
-            "value": world * B * K / r["elapsed"], "unit": "rollouts/s", "n_gpus": world, "steps": K, "warmup": W,
-            "ms_per_step": r["elapsed"] / K * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value": value, "unit": "rollouts/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": r["elapsed"] / r["steps_timed"] * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "steps_timed": r["steps_timed"], "repeats": r["plan"]["repeats"], "timed_region_s": r["elapsed"],
+            "ranks_joined": joined, "dist_backend": (backend if world > 1 else None),
             "config": {"workload": f"horizon={N} SE(3) rollout + cost + thrust-gradient (+ fused batch argmin), "
                                    f"batch={B} per GPU per step, {S} independent steps per kernel launch "
                                    f"({'one multi-batch launch = grid.y' if S > 1 else 'one launch per step'}), "
                                    f"ring of {ring} distinct batches in HBM ({ring * slot_bytes / 2 ** 20:.0f} MiB), "
-                                   f"{'hipGraph replay' if r['graph'] else 'eager launches'}",
+                                   f"{'hipGraph replay' if r['graph'] else 'eager launches'}; a pass = ceil(steps / {S}) full launches, "
+                                   f"repeated {r['plan']['repeats']}x so the timed region lasts >= {a.min_ms:g} ms",
                        "horizon": N, "batch_per_gpu": B, "global_batch": world * B, "steps_per_launch": S, "ring": ring,
-                       "parallelism": f"batch-sharded x{world}, one bucketed all-reduce(MIN) of {K} keys"},
+                       "parallelism": f"batch-sharded x{world}, one bucketed all-reduce(MIN) of the step keys"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None if traffic is None else traffic[0],
-                         "traffic_source": None if traffic is None else f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": None if traffic is None else traffic[0] * per_launch_rollouts,
+                         "traffic_over_algorithmic": None if traffic is None else traffic[0] / bytes_per_rollout,
+                         "traffic_source": None if traffic is None else f"profiles/{traffic[1]} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                                                          f"HBM bytes per rollout of this kernel at this launch shape x rollouts per launch)",
                          "kernel": "se3mpc::rollout_kernel<float, 30, REG, SPLIT, GRAD>", "kernel_us": r["launch_ms"] * 1e3,
                          "launches": r["nlaunch"], "rollouts_per_launch": per_launch_rollouts,
                          "bytes_per_launch": bytes_per_rollout * per_launch_rollouts,
@@ -288,10 +435,17 @@ def main():
         if "single_launch" in results:
             q = results["single_launch"]
             g1 = bytes_per_rollout * B / (q["launch_ms"] * 1e-3) / 1e9
-            res["single_launch"] = {"what": "the same K steps, ONE kernel launch per 8192-rollout step (sequentially dependent iterations)",
-                                    "value": world * B * K / q["elapsed"], "ms_per_step": q["elapsed"] / K * 1e3,
+            res["single_launch"] = {"what": "ONE kernel launch per 8192-rollout step (sequentially dependent iterations), same pass/repeat rule",
+                                    "value": world * B * q["steps_timed"] / q["elapsed"], "ms_per_step": q["elapsed"] / q["steps_timed"] * 1e3,
+                                    "steps_timed": q["steps_timed"], "repeats": q["plan"]["repeats"],
                                     "kernel_us": q["launch_ms"] * 1e3, "achieved_GB_per_s": g1, "frac": g1 / HBM_PEAK_GBPS,
                                     "keys_valid": q["keys_valid"]}
+        if iter_stats is not None:
+            res["iterated"] = iter_stats
+        if config_stats is not None:
+            res["configs"] = config_stats
+        if loop_stats is not None:
+            res["closed_loop"] = loop_stats
         if solve_stats is not None:
             res["solve"] = solve_stats
         if voxel_stats is not None:
@@ -300,18 +454,11 @@ def main():
             res["sweep"] = sweep(torch, ops, prm, dev, N)
         if cpu_stats is not None:
             res["cpu_baseline"] = cpu_stats
+            res["vs_cpu_baseline"] = value / cpu_stats["value"]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-
-
-def _launch_sizes(nsteps, per_launch, ring):
-    i = 0
-    while i < nsteps:
-        n = min(per_launch, nsteps - i, ring - (i % ring))
-        yield n
-        i += n
 
 
 def solve_leg(torch, ops, dev, B, N, rank, world):
@@ -402,11 +549,11 @@ def obstacle_source_leg(torch, ops, dev):
             "voxels": len(m.map), "table_capacity": m.map.capacity}
 
 
-def profiled_traffic(B, N, S):
-    """HBM bytes per launch of the timed kernel from the committed rocprofv3 PMC passes
-    (profiles/rNN_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, same command
-    without the graph) -- PMC counters cannot be read from inside this process.  None if no profile
-    of this exact workload is committed."""
+def profiled_traffic(B, N):
+    """HBM bytes PER ROLLOUT of the timed kernel at the timed launch shape, from the newest committed rocprofv3
+    PMC passes (profiles/rNN_traffic.json: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes, same command
+    without the graph) -- PMC counters cannot be read from inside this process.  None if no profile of this
+    workload is committed.  -> (bytes_per_rollout, file name)"""
     import glob
     best = None
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json"))):
@@ -414,9 +561,79 @@ def profiled_traffic(B, N, S):
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("batch") == B and d.get("horizon") == N and d.get("steps_per_launch", 1) == S:
-            best = (float(d["traffic_bytes_per_launch"]), os.path.basename(f))
+        if d.get("batch") == B and d.get("horizon") == N and d.get("steps_per_launch", 1) == 64:
+            best = (float(d["traffic_bytes_per_launch"]) / float(d["rollouts_per_launch"]), os.path.basename(f))
     return best
+
+
+def config_legs(torch, ops, dev, min_ms):
+    """BASELINE.json configs 2 and 3 as their own legs, each with its own roofline:
+      cfg2: batch 1024, horizon 30, rollout + thrust gradient, f32          -- 4*(6N+10) B per rollout
+      cfg3: batch 8192, horizon 50, K = 16 mapper spheres fused (cmin, viol) -- 4*(6N+12) B per rollout
+    `single` = one launch per batch (what one planner sees), `batched` = 64 independent batches per launch
+    (grid.y).  Inputs cycle through a ring of distinct batches larger than the Infinity Cache; launches are
+    replayed from a hipGraph; time = HIP events around the replays on the launch stream."""
+    from dart_planner_amd.capi import Params
+    out = {}
+    S = 64
+    for name, N, B, nsph in (("cfg2", 30, 1024, 0), ("cfg3", 50, 8192, 16)):
+        prm = Params.reference_defaults(horizon=N)
+        slot = 4 * B * ((9 + 3 * N) + (1 + 3 * N) + (2 if nsph else 0))
+        ring = S * max(2, math.ceil(math.ceil(320 * 2 ** 20 / slot) / S))
+        p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=21 + N)
+        g = torch.Generator(device=dev); g.manual_seed(2)
+        sph = None
+        if nsph:
+            # spheres as the mapper produces them (SURVEY.md 8d cfg-3): radius 1.0, centres ~ U(0,15)^3 snapped to 0.5 m
+            sph = torch.cat([torch.round(torch.rand(nsph, 3, device=dev, generator=g) * 30) / 2, torch.ones(nsph, 1, device=dev)], 1).contiguous()
+            cmin, viol = torch.empty(ring, B, device=dev), torch.empty(ring, B, device=dev)
+        bpr = 4 * (6 * N + (12 if nsph else 10))
+        legs = {}
+        for mode, per_l in (("single", 1), ("batched", S)):
+            def one(i0):
+                s0 = i0 % ring
+                if nsph:
+                    if per_l == 1:
+                        ops.rollout_obstacles(prm, p0[s0], v0[s0], goal[s0], T[s0], sph, out=(cost[s0], grad[s0], cmin[s0], viol[s0]))
+                    else:
+                        ops.rollout_obstacles_batched(prm, p0[s0:s0 + per_l], v0[s0:s0 + per_l], goal[s0:s0 + per_l], T[s0:s0 + per_l], sph,
+                                                      cost[s0:s0 + per_l], grad[s0:s0 + per_l], cmin[s0:s0 + per_l], viol[s0:s0 + per_l])
+                elif per_l == 1:
+                    ops.rollout_cost_grad(prm, p0[s0], v0[s0], goal[s0], T[s0], out=(cost[s0], grad[s0]))
+                else:
+                    ops.rollout_cost_grad_batched(prm, p0[s0:s0 + per_l], v0[s0:s0 + per_l], goal[s0:s0 + per_l], T[s0:s0 + per_l],
+                                                  cost[s0:s0 + per_l], grad[s0:s0 + per_l])
+            nl = ring // per_l                                   # launches per graph: one sweep of the ring
+            nl = min(nl, MAX_GRAPH_NODES)
+            body = lambda: [one(i * per_l) for i in range(nl)]
+            body(); torch.cuda.synchronize()
+            graph = capture(torch, dev, body)
+            ms1 = device_ms(torch, graph.replay, 2)
+            reps = max(2, math.ceil(min_ms / max(ms1, 1e-6)))
+            ms = device_ms(torch, graph.replay, reps) / nl
+            del graph
+            gbps = bpr * B * per_l / (ms * 1e-3) / 1e9
+            legs[mode] = {"launch_us": ms * 1e3, "rollouts_per_launch": B * per_l, "rollouts_per_s": B * per_l / (ms * 1e-3),
+                          "launches_timed": reps * nl,
+                          "roofline": {"bound": "hbm", "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
+                                       "bytes_per_rollout": bpr}}
+        out[name] = {"workload": f"horizon={N}, batch={B}, f32 rollout + cost + thrust gradient" + (f" fused with {nsph} sphere-obstacle residuals (min, violation)" if nsph else ""),
+                     "ring": ring, **legs}
+        del p0, v0, goal, T, cost, grad
+        torch.cuda.empty_cache()
+    return out
+
+
+def iterated_leg(torch, ops, dev, B, N, min_ms):
+    if not hasattr(ops, "rollout_iterate"):
+        return None
+    return None
+
+
+def closed_loop_leg(torch, ops, dev):
+    if not hasattr(ops, "closed_loop"):
+        return None
+    return None
 
 
 def sweep(torch, ops, prm, dev, N):

@@ -393,8 +393,12 @@ __global__ void extract_kernel(DevParams<R> q, int B, int ld, const R* __restric
 //   REV  any N: O(1) registers; the reverse sweep re-reads T_k (L2) and inverts the recurrence
 //        (V_k = V_{k+1} - a_k dt, P_k = P_{k+1} - V_k dt - a_k dt^2/2) instead of storing states.
 // ------------------------------------------------------------------------------------------
+// Monotone map float -> uint32 (a < b  <=>  bits(a) < bits(b)) for the packed argmin keys.  NaN of either sign maps
+// to 0xFFFFFFFE: above every real cost (+inf is 0xFF800000), below the dead-lane sentinel 0xFFFFFFFF -- a diverged
+// trajectory can neither win the argmin (a negative NaN would otherwise sort below -inf) nor pass for a dead lane.
 __device__ __forceinline__ uint32_t orderable_bits(float c) {
   const uint32_t u = __float_as_uint(c);
+  if (c != c) return 0xFFFFFFFEu;
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
@@ -699,6 +703,15 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
                          R* __restrict__ gradT, const R* __restrict__ spheres, int K, R* __restrict__ cmin,
                          R* __restrict__ viol, unsigned long long* __restrict__ key, uint32_t index_base) {
   HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  {                                                         // blockIdx.y = batch of a multi-batch launch (as rollout_kernel)
+    const size_t bi = blockIdx.y, ss = (size_t)3 * ld, st = (size_t)3 * q.N * ld;
+    p0 += bi * ss; v0 += bi * ss; T += bi * st; cost += bi * (size_t)ld;
+    if (goal != nullptr) goal += bi * ss;
+    if (GRAD) gradT += bi * st;
+    if (cmin != nullptr) cmin += bi * (size_t)ld;
+    if (viol != nullptr) viol += bi * (size_t)ld;
+    if (key != nullptr) key += bi * (size_t)gridDim.x;
+  }
   const int Kpad = (K + kSphereChunk - 1) / kSphereChunk * kSphereChunk;
   R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]
   R* sph = tile + (size_t)3 * q.N * kWave;                   // [Kpad][4] = (cx, cy, cz, (r + margin)^2)
@@ -1237,8 +1250,8 @@ int rollout_cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
 template <typename R>
 int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, const R* goal, const R* T,
                            R* cost, R* gradT, const R* spheres, int K, R* cmin, R* viol, uint64_t* key64, uint32_t index_base,
-                           void* stream) {
-  if (K < 0 || K > SE3MPC_MAX_SPHERES) return SE3MPC_ERR_SHAPE;
+                           int nbatch, void* stream) {
+  if (K < 0 || K > SE3MPC_MAX_SPHERES || nbatch < 1 || nbatch > 65535) return SE3MPC_ERR_SHAPE;
   int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
@@ -1250,13 +1263,13 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   // 8 wavefronts per workgroup while that still leaves SIMDs idle (the chip holds 1024 single-wave slots
   // before any wavefront has to share a SIMD), 3 otherwise; se3mpc_set_rollout_variant(+128 / +256) forces 3 / 8
   const int wsel = (g_rollout_variant >> 7) & 3;
-  const bool wide = wsel == 2 || (wsel == 0 && (long long)nblk * 8 <= 1024);
+  const bool wide = wsel == 2 || (wsel == 0 && (long long)nblk * nbatch * 8 <= 1024);
   const int W = wide ? 8 : 3;
   const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
   hipStream_t s = (hipStream_t)stream;
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
 #define SE3MPC_OBST_W(NN, REG, GRAD, WW)                                                                                 \
-  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW>), dim3(nblk), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
+  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW>), dim3(nblk, nbatch), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
                      goal, T, cost, gradT, spheres, K, cmin, viol, key, index_base)
 #define SE3MPC_OBST(NN, REG, GRAD) \
   if (wide) SE3MPC_OBST_W(NN, REG, GRAD, 8); else SE3MPC_OBST_W(NN, REG, GRAD, 3)
@@ -1415,7 +1428,14 @@ using namespace se3mpc;
                                                 R* cmin, R* viol, uint64_t* wave_keys, uint32_t index_base,              \
                                                 void* stream) {                                                          \
     return rollout_obstacles_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, spheres, K, cmin, viol, wave_keys,          \
-                                     index_base, stream);                                                                \
+                                     index_base, 1, stream);                                                             \
+  }                                                                                                                      \
+  extern "C" int se3mpc_rollout_obstacles_batched_##SUF(const se3mpc_params* p, int B, int ld, int nbatch, const R* p0,  \
+                                                        const R* v0, const R* goal, const R* T, R* cost, R* gradT,       \
+                                                        const R* spheres, int K, R* cmin, R* viol, uint64_t* wave_keys,  \
+                                                        uint32_t index_base, void* stream) {                             \
+    return rollout_obstacles_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, spheres, K, cmin, viol, wave_keys,          \
+                                     index_base, nbatch, stream);                                                        \
   }                                                                                                                      \
   extern "C" int se3mpc_is_plan_valid_##SUF(const se3mpc_params* p, int B, int ld, const R* P, const R* V,                \
                                             int32_t* valid, void* stream) {                                              \

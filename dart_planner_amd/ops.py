@@ -237,9 +237,10 @@ class Ops:
         return cost, gradT
 
     def rollout_obstacles(self, params: Params, p0, v0, goal, T, spheres, want_grad: bool = True, B: Optional[int] = None,
-                          wave_keys=None, index_base: int = 0):
+                          wave_keys=None, index_base: int = 0, out=None):
         """Rollout + cost (+ gradient) fused with the sphere-obstacle residuals of the rolled-out positions.
-        -> (cost (ld,), gradT (3N, ld) | None, cmin (ld,), viol (ld,))."""
+        -> (cost (ld,), gradT (3N, ld) | None, cmin (ld,), viol (ld,)).  ``out=(cost, gradT, cmin, viol)`` reuses
+        preallocated outputs."""
         N = params.horizon
         self._lane(p0, 3, "p0"); self._lane(v0, 3, "v0"); self._lane(T, 3 * N, "T")
         if params.has_goal:
@@ -249,10 +250,38 @@ class Ops:
         if spheres.ndim != 2 or spheres.shape[1] != 4 or spheres.shape[0] > SE3MPC_MAX_SPHERES or self.be.suffix(spheres) != suf:
             raise ValueError(f"spheres: expected (K<={SE3MPC_MAX_SPHERES}, 4) {suf}, got {tuple(spheres.shape)}")
         ld = T.shape[1]
-        cost = self.be.empty((ld,), suf)
-        gradT = self.be.empty((3 * N, ld), suf) if want_grad else None
-        cmin, viol = self.be.empty((ld,), suf), self.be.empty((ld,), suf)
+        if out is not None:
+            cost, gradT, cmin, viol = out
+        else:
+            cost = self.be.empty((ld,), suf)
+            gradT = self.be.empty((3 * N, ld), suf) if want_grad else None
+            cmin, viol = self.be.empty((ld,), suf), self.be.empty((ld,), suf)
         self.lib.call("rollout_obstacles", suf, self._B(ld, B), ld, self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost), self.be.ptr(gradT),
+                      self.be.ptr(spheres), spheres.shape[0], self.be.ptr(cmin), self.be.ptr(viol), self.be.ptr(wave_keys),
+                      int(index_base), self.be.stream(), params=params)
+        return cost, gradT, cmin, viol
+
+    def rollout_obstacles_batched(self, params: Params, p0, v0, goal, T, spheres, cost, gradT, cmin, viol, wave_keys=None,
+                                  index_base: int = 0):
+        """`nbatch` independent batches of the fused rollout + obstacle kernel in one launch (one shared sphere table).
+        p0, v0, goal: (nbatch, 3, ld); T, gradT: (nbatch, 3N, ld); cost, cmin, viol: (nbatch, ld); caller-allocated."""
+        N = params.horizon
+        nb, _, ld = T.shape
+        for a, shp, nm in ((p0, (nb, 3, ld), "p0"), (v0, (nb, 3, ld), "v0"), (T, (nb, 3 * N, ld), "T"), (cost, (nb, ld), "cost"),
+                           (gradT, (nb, 3 * N, ld), "gradT"), (cmin, (nb, ld), "cmin"), (viol, (nb, ld), "viol")):
+            if a is None and nm in ("gradT", "cmin", "viol"):
+                continue
+            self.be.check(a, nm)
+            if tuple(a.shape) != shp:
+                raise ValueError(f"{nm}: expected {shp}, got {tuple(a.shape)}")
+        if params.has_goal:
+            self.be.check(goal, "goal")
+        suf = self.be.suffix(T)
+        self.be.check(spheres, "spheres")
+        if spheres.ndim != 2 or spheres.shape[1] != 4 or spheres.shape[0] > SE3MPC_MAX_SPHERES or self.be.suffix(spheres) != suf:
+            raise ValueError(f"spheres: expected (K<={SE3MPC_MAX_SPHERES}, 4) {suf}, got {tuple(spheres.shape)}")
+        self.lib.call("rollout_obstacles_batched", suf, ld, ld, nb, self.be.ptr(p0), self.be.ptr(v0),
                       self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(cost), self.be.ptr(gradT),
                       self.be.ptr(spheres), spheres.shape[0], self.be.ptr(cmin), self.be.ptr(viol), self.be.ptr(wave_keys),
                       int(index_base), self.be.stream(), params=params)

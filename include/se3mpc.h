@@ -200,6 +200,18 @@ int se3mpc_rollout_obstacles_f64(const se3mpc_params* p, int B, int ld, const do
                                  const double* goal, const double* T, double* cost, double* gradT, const double* spheres,
                                  int K, double* cmin, double* viol, uint64_t* wave_keys, uint32_t index_base, void* stream);
 
+/* Multi-batch launch of the fused kernel (grid.y = batch), operands laid out as in se3mpc_rollout_cost_grad_batched_*:
+ * p0, v0, goal: [nbatch][3][ld]; T, gradT: [nbatch][3N][ld]; cost, cmin, viol: [nbatch][ld]; wave_keys: NULL or
+ * [nbatch][ceil(B/64)]; ONE sphere table [K][4] shared by all batches.  1 <= nbatch <= 65535. */
+int se3mpc_rollout_obstacles_batched_f32(const se3mpc_params* p, int B, int ld, int nbatch, const float* p0,
+                                         const float* v0, const float* goal, const float* T, float* cost, float* gradT,
+                                         const float* spheres, int K, float* cmin, float* viol, uint64_t* wave_keys,
+                                         uint32_t index_base, void* stream);
+int se3mpc_rollout_obstacles_batched_f64(const se3mpc_params* p, int B, int ld, int nbatch, const double* p0,
+                                         const double* v0, const double* goal, const double* T, double* cost, double* gradT,
+                                         const double* spheres, int K, double* cmin, double* viol, uint64_t* wave_keys,
+                                         uint32_t index_base, void* stream);
+
 /* keys_out[i] = min over wave_keys[i][0..per_batch) for i < nbatch (one small workgroup per batch). */
 int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uint64_t* keys_out, void* stream);
 

@@ -191,6 +191,18 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
     co2, g_none, cmn2, _ = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
                                                    h.prob(np.zeros((0, 4))), want_grad=False)
     assert g_none is None and np.all(np.isinf(h.to_host(cmn2))) and np.allclose(h.to_host(co2), h.to_host(co), rtol=t["cost_rel"])
+    # multi-batch launch of the fused kernel == the same batches one by one (shared sphere table, per-batch keys)
+    cob = h.to_dev(np.zeros((nb, B), dtype=h.dt)); gob = h.to_dev(np.zeros((nb, 3 * N, B), dtype=h.dt))
+    cmb = h.to_dev(np.zeros((nb, B), dtype=h.dt)); vib = h.to_dev(np.zeros((nb, B), dtype=h.dt))
+    wkb = h.to_dev(np.zeros((nb, (B + 63) // 64), dtype=np.int64))
+    h.ops.rollout_obstacles_batched(prm, dp0, dv0, dgoal, dT, h.prob(sph[:9]), cob, gob, cmb, vib, wave_keys=wkb, index_base=3)
+    h.ops.reduce_keys(wkb, keysb)
+    for i in range(nb):
+        ci, gi, mi, vi = h.ops.rollout_obstacles(prm, h.lane(bp0[i], B), h.lane(bv0[i], B), h.lane(bgoal[i], B), h.lane(bT[i], B),
+                                                 h.prob(sph[:9]))
+        for got, one in ((cob, ci), (gob, gi), (cmb, mi), (vib, vi)):
+            assert np.array_equal(h.to_host(got)[i], h.to_host(one)), "batched fused rollout"
+        assert h.ops.lib.key_index(int(h.to_host(keysb)[i]) & 0xFFFFFFFFFFFFFFFF) == 3 + int(np.argmin(h.to_host(ci)))
     # the rolled-out states satisfy the reference's dynamics constraints (a8 == 0)
     Xr = orc.pack(P_ref, V_ref, T)
     Rr = h.ops.dynamics_residual(prm, h.lane(Xr, B), h.lane(p0, B), h.lane(v0, B))
@@ -208,6 +220,47 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
     assert h.ops.decode_key(key)[0] == 5 + int(np.argmin(h.to_host(f)))
     Xt = h.ops.transpose(h.prob(X))
     assert np.array_equal(h.to_host(Xt), X.astype(h.dt).T)
+
+
+def check_key_nonfinite(h: Harness):
+    """Packed argmin keys with non-finite costs: NaN of either sign must never win (a negative NaN would sort below
+    -inf in a plain sign-magnitude map) nor pass for the dead-lane sentinel; -inf wins over everything real; +inf
+    loses to everything real.  Through se3mpc_argmin_*, the key fused into the rollout and se3mpc_reduce_keys."""
+    B = 130
+    nan_pos = np.float32(np.nan)
+    nan_neg = np.frombuffer(np.uint32(0xFFC00001).tobytes(), dtype=np.float32)[0]
+    nan_full = np.frombuffer(np.uint32(0x7FFFFFFF).tobytes(), dtype=np.float32)[0]
+    for dt in (np.float32, np.float64):
+        base = np.linspace(5.0, 9.0, B).astype(dt)
+        for name, fill, expect in (("nan", [nan_pos, nan_neg, nan_full], 3), ("+inf", [np.inf], 1), ("-inf", [-np.inf], 0)):
+            c = base.copy()
+            c[:len(fill)] = np.asarray(fill, dtype=dt)
+            c[64] = dt(4.0)                                    # the finite minimum sits in the second wavefront
+            key = h.ops.argmin(h.to_dev(c), index_base=100)
+            idx, kc = h.ops.decode_key(key)
+            if name == "-inf":
+                assert idx == 100 and kc == -np.inf, (name, dt, idx, kc)
+            else:
+                assert idx == 164 and kc == 4.0, (name, dt, idx, kc)
+        # every cost NaN: the key is the NaN code with a REAL index (not the sentinel), so a caller can tell
+        # "all diverged" from "no live lane"
+        key = h.ops.argmin(h.to_dev(np.full(B, np.nan, dtype=dt)), index_base=0)
+        k = int(h.to_host(key)[0]) & 0xFFFFFFFFFFFFFFFF
+        assert (k >> 32) == 0xFFFFFFFE and (k & 0xFFFFFFFF) < B
+    # fused into the rollout: a NaN goal makes trajectory 5's cost NaN; another trajectory must win
+    N = 6
+    prm = Params.reference_defaults(horizon=N)
+    rng = np.random.default_rng(4)
+    p0, v0, goal, T = random_batch(rng, B, N)
+    goal[5, 1] = np.nan
+    goal[70] = p0[70]; v0[70] = 0.0                            # cheap trajectory
+    key = h.to_dev(np.array([-1], dtype=np.int64))
+    hh = Harness(h.ops, h.to_dev, h.to_host, np.float32)
+    cost, *_ = h.ops.rollout_cost_grad(prm, hh.lane(p0, B), hh.lane(v0, B), hh.lane(goal, B), hh.lane(T, B), want_grad=False, key=key)
+    ch = h.to_host(cost)
+    assert np.isnan(ch[5]) and np.isfinite(np.delete(ch, 5)).all()
+    idx, kc = h.ops.decode_key(key)
+    assert idx == int(np.nanargmin(ch)) and kc == np.nanmin(ch)
 
 
 # --------------------------------------------------------------------------------------- solver

@@ -92,3 +92,42 @@ def test_two_rank_restart_argmin_matches_single_process():
         assert owner == (0 if restart < 3 else 1)                      # shards: rank 0 -> [0,3), rank 1 -> [3,5)
         # MIN of the unsigned keys: step 0 -> rank 0's (cost bits 100), step 1 -> rank 1's (cost bits 49)
         assert keys == [((0x80000000 | 100) << 32) | 1, ((0x80000000 | 49) << 32) | 12]
+
+
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` without a torchrun environment must start 2 ranks as a child process and report
+    them (dry run: rank plumbing only, gloo, no HIP) -- a driver that calls bench.py directly gets a real N-rank run
+    or a non-zero exit, never a 1-rank line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "20", "--warmup", "5"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_joined"] == 2 and d["steps"] == 20 and d["keys_valid"] is True
+    # --gpus N under a torchrun environment of another size is refused, not silently relabelled
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], env=env2,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr
+
+
+def test_bench_timed_plan_shape_does_not_depend_on_steps():
+    """The timed region is built from FULL launches repeated to a minimum duration, whatever --steps says."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for K in (1, 20, 64, 65, 20000):
+        lpp = -(-K // 64)
+        p = bench.timed_plan(K, 64, pass_ms=0.065 * lpp, min_ms=20.0)
+        assert p["launches_per_pass"] == lpp and p["steps_per_pass"] == 64 * lpp
+        assert p["repeats"] * 0.065 * lpp >= 20.0 and p["passes_per_graph"] * lpp <= bench.MAX_GRAPH_NODES
+    p = bench.timed_plan(20, 1, pass_ms=20 * 0.0045, min_ms=20.0)
+    assert p["launches_per_pass"] == 20 and p["repeats"] * 20 * 0.0045 >= 20.0

@@ -35,6 +35,10 @@ def test_lane_kernels(emu_ops, dt, N, B):
     pc.check_lane_kernels(harness(emu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5, 6))
 
 
+def test_keys_with_nonfinite_costs(emu_ops):
+    pc.check_key_nonfinite(harness(emu_ops, np.float32))
+
+
 def test_lane_kernels_other_dt(emu_ops):
     pc.check_lane_kernels(harness(emu_ops, np.float64), 20, 8, seed=2, dt=0.05)
 

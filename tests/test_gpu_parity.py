@@ -48,6 +48,10 @@ def test_population_sums(gpu_ops, dt, rows, B):
     pc.check_population_sums(harness(gpu_ops, dt), rows=rows, B=B, seed=rows)
 
 
+def test_keys_with_nonfinite_costs(gpu_ops):
+    pc.check_key_nonfinite(harness(gpu_ops, np.float32))
+
+
 def test_lane_kernels_other_dt(gpu_ops):
     pc.check_lane_kernels(harness(gpu_ops, np.float64), 20, 300, seed=2, dt=0.05)
     pc.check_lane_kernels(harness(gpu_ops, np.float32), 20, 300, seed=2, dt=0.1)
