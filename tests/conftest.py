@@ -40,3 +40,10 @@ def golden_mapper():
     data = np.load(os.path.join(GOLDEN, "mapper_spheres.npz"))
     meta = json.load(open(os.path.join(GOLDEN, "mapper_spheres.json")))
     return data, meta
+
+
+@pytest.fixture(scope="session")
+def golden_cfg1():
+    data = np.load(os.path.join(GOLDEN, "cfg1_solves.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "cfg1_solves.json")))
+    return data, meta

@@ -293,6 +293,36 @@ def check_solver_golden(h: Harness, data, meta, keys=None):
     return worst
 
 
+def cfg1_params(meta) -> Params:
+    return Params.reference_defaults(horizon=meta["N"], dt=meta["dt"], max_velocity=meta["max_velocity"],
+                                     max_acceleration=meta["max_acceleration"], max_iterations=meta["maxiter"], pgtol=meta["tol"],
+                                     ftol=10 * meta["tol"])
+
+
+def check_solver_cfg1(h: Harness, data, meta, rows=None):
+    """BASELINE.json config 1's exact problem set (tests/golden/make_golden_cfg1.py: horizon 20, |v| <= 8 box, state
+    (0,0,1), the contract goal + 100 x U(-5,5)^3) in ONE batched launch against what the reference returned: iteration
+    and evaluation counts and status exactly, positions to the stated tolerance, trajectory arrays."""
+    t = h.tol
+    prm = cfg1_params(meta)
+    N = meta["N"]
+    rows = np.arange(meta["n"]) if rows is None else np.asarray(rows)
+    B = len(rows)
+    goals = data["goals_used"][rows]
+    out = h.ops.solve(prm, h.prob(np.tile(data["p0"], (B, 1))), h.prob(np.tile(data["v0"], (B, 1))), h.prob(goals))
+    info = h.ops.info_to_host(out["info"])
+    got = np.stack([info["nit"], info["nfev"], info["status"]], axis=1)
+    assert np.array_equal(got, data["info"][rows]), "nit / nfev / status"
+    x = h.to_host(out["x"]).astype(float)
+    assert np.max(np.abs(x[:, :6 * N] - data["x"][rows][:, :6 * N])) <= t["pos"], "x[P,V]"
+    assert np.max(np.abs(x[:, 6 * N:] - data["x"][rows][:, 6 * N:])) <= t["thrust"], "x[T]"
+    assert np.max(np.abs(x[:, 3 * N:6 * N])) <= meta["max_velocity"] + 1e-12, "velocity box of this configuration"
+    assert np.max(np.abs(info["fun"] - data["fun"][rows]) / np.abs(data["fun"][rows])) <= 1e-5
+    for name, tl in (("accelerations", t["thrust"]), ("attitudes", t["pos"] * 100), ("thrusts", t["thrust"]), ("body_rates", t["rates"])):
+        assert np.max(np.abs(h.to_host(out[name]).astype(float) - data[name][rows])) <= tl, name
+    return float(np.max(np.abs(x[:, :3 * N] - data["positions"][rows].reshape(B, -1))))
+
+
 def check_solver_extraction(h: Harness, N: int, B: int, seed: int = 3):
     """pgtol = inf makes L-BFGS-B return the projected x0 untouched, which isolates the solver's
     own cold-start / projection / extraction code on arbitrary thrust sequences."""

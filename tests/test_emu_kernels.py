@@ -53,6 +53,13 @@ def test_solver_reproduces_reference_solves(emu_ops, golden_solve, dt):
     assert worst <= (1e-4 if dt == np.float32 else 1e-9)
 
 
+def test_solver_config1_sample(emu_ops, golden_cfg1):
+    data, meta = golden_cfg1
+    two_its = [int(i) for i in np.nonzero(data["info"][:, 0] != 1)[0]]          # the one solve that takes two iterations
+    worst = pc.check_solver_cfg1(harness(emu_ops, np.float64), data, meta, rows=[0, 1, 2] + two_its)
+    assert worst <= 1e-9
+
+
 def test_batched_solve_matches_scipy_odd_horizons(emu_ops):
     # horizons that are not template instantiations (J = 2, 5 with padding lanes), a few problems each
     for N, B in ((13, 6), (33, 4)):

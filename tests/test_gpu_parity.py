@@ -66,6 +66,33 @@ def test_solver_reproduces_every_reference_solve(gpu_ops, golden_solve, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_config1_exact_problem_set(gpu_ops, golden_cfg1, dt):
+    """BASELINE.json config 1: all 101 reference solves of the horizon-20 / |v| <= 8 configuration in one launch."""
+    data, meta = golden_cfg1
+    worst = pc.check_solver_cfg1(harness(gpu_ops, dt), data, meta)
+    print(f"config 1, {np.dtype(dt).name}: worst position error vs the reference {worst:.3e} m")
+    assert worst <= (1e-4 if dt == np.float32 else 1e-9)
+
+
+def test_planner_mirror_config1_sequence(gpu_ops, golden_cfg1):
+    """The same set the way the reference's test runs it: ONE planner object (the cloud controller's configuration),
+    plan_trajectory goal after goal, goal hysteresis in force -> the reference's trajectories."""
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCConfig, SE3MPCPlanner
+    from dart_planner_amd.common.types import DroneState
+    data, meta = golden_cfg1
+    pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=20, dt=0.1, max_velocity=8.0, max_acceleration=4.0, position_weight=100.0,
+                                    velocity_weight=10.0, obstacle_weight=1000.0, safety_margin=1.5))
+    st = DroneState(timestamp=0.0, position=data["p0"].copy(), velocity=data["v0"].copy())
+    for i, g in enumerate(data["goals_asked"]):
+        tr = pl.plan_trajectory(st, g.copy())
+        assert np.array_equal(pl.goal_position, data["goals_used"][i])
+        assert (pl.last_result["nit"], pl.last_result["nfev"], pl.last_result["status"]) == tuple(int(v) for v in data["info"][i])
+        assert np.max(np.abs(np.asarray(tr.positions) - data["positions"][i])) <= 1e-9
+        assert np.max(np.abs(np.asarray(tr.velocities) - data["velocities"][i])) <= 1e-9
+        assert np.max(np.abs(np.asarray(tr.thrusts) - data["thrusts"][i])) <= 1e-7
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
 @pytest.mark.parametrize("N", [6, 20, 30, 50, 64])
 def test_solver_extraction_and_cold_start(gpu_ops, dt, N):
     pc.check_solver_extraction(harness(gpu_ops, dt), N, 37)
@@ -130,6 +157,29 @@ def test_full_size_rollout_properties(gpu_ops):
         Cm, cmin, viol = ops.obstacle_residual(prm, X, sph)
         assert torch.equal(Cm.min(0).values, cmin)                                  # (5)
         assert float((viol - torch.clamp(-Cm, min=0).sum(0)).abs().max()) <= 1e-3 * max(1.0, float(viol.max()))
+        # (6) the FUSED kernel at this size (config 3 is N = 50, B = 8192, K = 16): every trajectory against the
+        # unfused pair above (same cost / gradient; min and violation of the materialised residuals of the same
+        # rolled-out states), and a 256-trajectory sample against the oracle
+        wk = torch.zeros((B + 63) // 64, dtype=torch.int64, device=dev)
+        fc, fg, fmin, fviol = ops.rollout_obstacles(prm, p0, v0, goal, T, sph, wave_keys=wk, index_base=0)
+        assert float(((fc - cost).abs() / cost).max()) <= 1e-6 and float((fg - gT).abs().max()) <= 1e-5 * float(gT.abs().max())
+        assert float((fmin - cmin).abs().max()) <= 2e-4 * max(1.0, float(cmin.abs().max()))
+        assert float((fviol - viol).abs().max()) <= 1e-3 * max(1.0, float(viol.max()))
+        fk = torch.zeros(1, dtype=torch.int64, device=dev)
+        ops.reduce_keys(wk.view(1, -1), fk)
+        assert ops.decode_key(fk)[0] == int(torch.argmin(fc))
+        cfg = orc.OracleConfig(prediction_horizon=N)
+        pick = np.random.default_rng(N).choice(B, 256, replace=False)
+        hst = lambda a: a[:, pick].double().cpu().numpy().T
+        Tn = hst(T).reshape(256, N, 3)
+        c_ref, g_ref = orc.rollout_cost_grad(hst(p0), hst(v0), hst(goal), Tn, cfg)
+        P_ref, V_ref = orc.rollout(hst(p0), hst(v0), Tn, cfg)
+        sp = sph.double().cpu().numpy()
+        C_ref = orc.obstacle_residual(orc.pack(P_ref, V_ref, Tn), sp[:, :3], sp[:, 3], cfg)
+        assert np.max(np.abs(fc[pick].cpu().numpy() - c_ref) / c_ref) <= 5e-6
+        assert np.max(np.abs(hst(fg).reshape(256, N, 3) - g_ref)) <= 5e-6 * np.max(np.abs(g_ref))
+        assert np.max(np.abs(fmin[pick].cpu().numpy() - C_ref.min(1))) <= 2e-5 * max(1.0, np.max(np.abs(C_ref)))
+        assert np.max(np.abs(fviol[pick].cpu().numpy() - np.maximum(0, -C_ref).sum(1))) <= 4e-5 * max(1.0, np.max(np.abs(C_ref)))
 
 
 def test_monte_carlo_restarts_f64_vs_f32(gpu_ops):
@@ -260,6 +310,31 @@ def test_monte_carlo_full_size(gpu_ops):
     assert same.mean() >= 0.98
     err = (o64["x"] - x[sub].reshape(-1, 9 * N).double()).abs()[torch.from_numpy(same).to(dev)][:, :3 * N].max()
     assert float(err) <= 1e-4
+    # 512 PERTURBED restarts (never restart 0) against SciPy from the same x0, problem by problem: the f64 solve must
+    # follow SciPy exactly (nit, nfev, status; positions <= 1e-9 m), the f32 solve of the full-size launch within
+    # the north_star tolerance wherever it took the same path
+    cfg = orc.OracleConfig(prediction_horizon=N)
+    rng = np.random.default_rng(3)
+    si, ri = rng.integers(0, S, 512), rng.integers(1, Rr, 512)
+    flat = torch.from_numpy(si * Rr + ri).to(dev)
+    X0s = X0.reshape(S * Rr, 9 * N)[flat]
+    o64 = ops.solve(prm, d(p0[si]), d(v0[si]), d(goal[si]), x0=d(X0s), want_trajectory=False)
+    i64 = ops.info_to_host(o64["info"])
+    x64 = o64["x"].cpu().numpy()
+    x32 = x.reshape(S * Rr, 9 * N)[flat].cpu().numpy().astype(float)
+    i32 = info.reshape(-1)[si * Rr + ri]
+    hp0, hv0, hg, hx0 = (a.double().cpu().numpy() for a in (p0[si], v0[si], goal[si], X0s))
+    worst64 = worst32 = 0.0
+    same32 = 0
+    for j in range(512):
+        xr, ir = orc.solve(hp0[j], hv0[j], hg[j], cfg, x0=hx0[j])
+        assert (int(i64["nit"][j]), int(i64["nfev"][j]), int(i64["status"][j])) == (ir["nit"], ir["nfev"], ir["status"]), j
+        worst64 = max(worst64, float(np.max(np.abs(x64[j, :3 * N] - xr[:3 * N]))))
+        if (int(i32["nit"][j]), int(i32["nfev"][j]), int(i32["status"][j])) == (ir["nit"], ir["nfev"], ir["status"]):
+            same32 += 1
+            worst32 = max(worst32, float(np.max(np.abs(x32[j, :3 * N] - xr[:3 * N]))))
+    print(f"config 5, 512 perturbed restarts vs SciPy: f64 {worst64:.2e} m, f32 {worst32:.2e} m ({same32}/512 on SciPy's path)")
+    assert worst64 <= 1e-9 and worst32 <= 1e-4 and same32 >= 0.98 * 512
 
 
 def test_wave_ops_selftest(gpu_ops):

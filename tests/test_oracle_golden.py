@@ -129,3 +129,19 @@ def test_shooting_rollout_is_pinned_by_reference_functions(golden_path):
             Tp[b, k, a] += eps; Tm[b, k, a] -= eps
             fd = (orc.rollout_cost(p0[b], v0[b], goal[b], Tp[b], cfg) - orc.rollout_cost(p0[b], v0[b], goal[b], Tm[b], cfg)) / (2 * eps)
             assert np.isclose(G[b, k, a], fd, rtol=1e-8, atol=1e-6), (N, b, k, a, G[b, k, a], fd)
+
+
+def test_oracle_reproduces_config1_solves(golden_cfg1):
+    """BASELINE.json config 1 (horizon 20, the cloud controller's |v| <= 8 box, 101 goals): the oracle's solve is
+    what the reference returned -- counts exactly, decision vectors and trajectory arrays to 1e-10."""
+    data, meta = golden_cfg1
+    cfg = orc.OracleConfig(prediction_horizon=meta["N"], dt=meta["dt"], max_velocity=meta["max_velocity"],
+                           max_acceleration=meta["max_acceleration"], max_iterations=meta["maxiter"], convergence_tolerance=meta["tol"])
+    assert np.array_equal(orc.bounds(cfg), data["bounds"])
+    for i in range(meta["n"]):
+        x, info = orc.solve(data["p0"], data["v0"], data["goals_used"][i], cfg)
+        assert (info["nit"], info["nfev"], info["status"]) == tuple(int(v) for v in data["info"][i])
+        assert np.max(np.abs(x - data["x"][i])) <= 1e-10
+        ex = orc.extract_solution(x, cfg)
+        for name in ("accelerations", "attitudes", "body_rates", "thrusts"):
+            assert np.max(np.abs(ex[name] - data[name][i])) <= 1e-9, name

@@ -8,16 +8,16 @@ TAG=${1:-r01}
 export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
-COMMON="--no-cpu-baseline --no-solve --no-obstacle-source"
-# 1. kernel trace + stats of the default bench command (both legs, hipGraph replay, K = 20000)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $COMMON > $OUT/bench_trace.log 2>&1
+COMMON="--no-cpu-baseline --no-solve --no-obstacle-source --no-configs --no-iterated --no-closed-loop"
+# 1. kernel trace + stats of the DRIVER's bench command (--steps 20 --warmup 5: both legs, hipGraph replay; the launch shape does not depend on --steps)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $COMMON --steps 20 --warmup 5 > $OUT/bench_trace.log 2>&1
 # 2./3. PMC passes (their own runs, kernel-trace only; eager launches so every dispatch is a plain kernel)
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${C}_fused -- python3 bench.py $COMMON --no-graph --no-single --steps 640 --warmup 64 > $OUT/pmc_${C}_fused.log 2>&1
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${C}_single -- python3 bench.py $COMMON --no-graph --steps-per-launch 1 --steps 200 --warmup 20 > $OUT/pmc_${C}_single.log 2>&1
-  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${C}_b4m -- python3 bench.py $COMMON --no-graph --steps-per-launch 1 --batch 4194304 --ring 2 --steps 20 --warmup 3 > $OUT/pmc_${C}_b4m.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${C}_fused -- python3 bench.py $COMMON --no-graph --no-single --steps 640 --warmup 64 --min-ms 1 > $OUT/pmc_${C}_fused.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${C}_single -- python3 bench.py $COMMON --no-graph --steps-per-launch 1 --steps 200 --warmup 20 --min-ms 1 > $OUT/pmc_${C}_single.log 2>&1
+  rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_${C}_b4m -- python3 bench.py $COMMON --no-graph --steps-per-launch 1 --batch 4194304 --ring 2 --steps 20 --warmup 3 --min-ms 1 > $OUT/pmc_${C}_b4m.log 2>&1
 done
 # 4. the solver kernel
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solve -- python3 bench.py --no-cpu-baseline --no-obstacle-source --no-single --steps 640 > $OUT/bench_solve.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/solve -- python3 bench.py --no-cpu-baseline --no-obstacle-source --no-single --no-configs --no-iterated --no-closed-loop --steps 640 > $OUT/bench_solve.log 2>&1
 python3 tools/summarize_profiles.py $OUT > gpurun_out/profile_summary_$TAG.json
 cat gpurun_out/profile_summary_$TAG.json
