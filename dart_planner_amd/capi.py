@@ -97,6 +97,51 @@ class VoxelMapDesc(C.Structure):
                 ("reserved", C.c_int32), ("resolution", C.c_double), ("prior", C.c_double)]
 
 
+class ControllerParams(C.Structure):
+    """struct se3mpc_controller_params == GeometricControllerConfig after its tuning profile
+    (src/dart_planner/control/geometric_controller.py:26-77, :140-158), unit-stripped."""
+    _fields_ = [("kp_pos", C.c_double * 3), ("ki_pos", C.c_double * 3), ("kd_pos", C.c_double * 3), ("kp_att", C.c_double * 3),
+                ("kd_att", C.c_double * 3), ("inertia", C.c_double * 3), ("max_torque_xyz", C.c_double * 3),
+                ("max_integral_per_axis", C.c_double * 3), ("max_integral_pos", C.c_double), ("max_tilt_angle", C.c_double),
+                ("mass", C.c_double), ("gravity", C.c_double), ("max_thrust", C.c_double), ("min_thrust", C.c_double),
+                ("tracking_error_threshold", C.c_double), ("velocity_error_threshold", C.c_double),
+                ("back_calculation_gain", C.c_double), ("integral_decay_factor", C.c_double), ("saturation_threshold", C.c_double),
+                ("yaw_singularity_threshold", C.c_double), ("default_heading_yaw", C.c_double),
+                ("anti_windup_method", C.c_int32), ("yaw_fallback_method", C.c_int32)]
+    ANTI_WINDUP = {"clamping": 0, "back_calculation": 1}
+    YAW_FALLBACK = {"skip_yaw": 0, "default_heading": 1, "maintain_current": 2}
+
+    @classmethod
+    def from_config(cls, cfg) -> "ControllerParams":
+        """From any object with GeometricControllerConfig's attribute names (the mirror's dataclass, the oracle's)."""
+        p = cls()
+        for name, ctype in cls._fields_:
+            if name == "anti_windup_method":
+                p.anti_windup_method = cls.ANTI_WINDUP.get(cfg.anti_windup_method, 2)
+            elif name == "yaw_fallback_method":
+                p.yaw_fallback_method = cls.YAW_FALLBACK.get(cfg.yaw_singularity_fallback_method, 3)
+            elif ctype is C.c_double:
+                setattr(p, name, float(getattr(cfg, name)))
+            else:
+                setattr(p, name, (C.c_double * 3)(*[float(v) for v in getattr(cfg, name)]))
+        return p
+
+
+class SimulatorParams(C.Structure):
+    """struct se3mpc_simulator_params == DroneSimulator.__init__ (src/dart_planner/utils/drone_simulator.py:41-50)."""
+    _fields_ = [("mass", C.c_double), ("gravity", C.c_double), ("inertia", C.c_double * 3), ("max_thrust", C.c_double),
+                ("max_torque", C.c_double)]
+
+    @classmethod
+    def reference_defaults(cls, **overrides) -> "SimulatorParams":
+        p = cls(mass=1.5, gravity=9.81, inertia=(C.c_double * 3)(0.1, 0.1, 0.2), max_thrust=20.0, max_torque=10.0)
+        for k, v in overrides.items():
+            setattr(p, k, v)
+        return p
+
+
+CONTROLLER_STATE_WORDS = 12
+
 _P = C.c_void_p
 _I = C.c_int
 _D = C.c_double
@@ -137,7 +182,21 @@ _VOXEL_PLAIN_API = {
     "se3mpc_voxel_export": (C.c_int, [_VP, _P, _P, _P, _P, _P]),
     "se3mpc_voxel_local_workspace": (C.c_int, [_I]),
 }
+_CP = C.POINTER(ControllerParams)
+_SP = C.POINTER(SimulatorParams)
+_LL = C.c_longlong
+# consumer side of the contract: se3mpc_<base>_<suffix>(...)
+_LOOP_TYPED_API = {
+    "control": [_CP, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "control_plan": [_CP, _I, _P, _P, _P, _P, _P, _P, _I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P],
+    "simulator_step": [_SP, _I, _D, _P, _P, _P, _LL, _P, _P, _P, _P, _P, _P],
+    "closed_loop": [_CP, _SP, _I, _I, _D, _I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _LL, _I,
+                    C.POINTER(C.c_double * 3), _I, _P, _P, _P, _P, _P],
+}
 _PLAIN_API = {
+    "se3mpc_controller_default_params": (C.c_int, [_CP]),
+    "se3mpc_simulator_default_params": (C.c_int, [_SP]),
+    "se3mpc_controller_reset": (C.c_int, [_CP, _I, _P, _P]),
     "se3mpc_abi_version": (C.c_int, []),
     "se3mpc_last_error": (C.c_char_p, []),
     "se3mpc_device_count": (C.c_int, []),
@@ -155,6 +214,8 @@ def exported_symbols() -> list:
     """Every symbol include/se3mpc.h declares (the CPU test-suite checks the .so exports them)."""
     names = list(_PLAIN_API)
     for base in _TYPED_API:
+        names += [f"se3mpc_{base}_f32", f"se3mpc_{base}_f64"]
+    for base in _LOOP_TYPED_API:
         names += [f"se3mpc_{base}_f32", f"se3mpc_{base}_f64"]
     names += list(_VOXEL_PLAIN_API)
     for base in _VOXEL_TYPED_API:
@@ -188,6 +249,10 @@ class Library:
                 fn = getattr(self._dll, f"se3mpc_{base}_{suf}")
                 fn.restype = C.c_int
                 fn.argtypes = ([_PP] if has_params else []) + args
+        for base, args in _LOOP_TYPED_API.items():
+            for suf in ("f32", "f64"):
+                fn = getattr(self._dll, f"se3mpc_{base}_{suf}")
+                fn.restype, fn.argtypes = C.c_int, args
         for name, (res, args) in _VOXEL_PLAIN_API.items():
             fn = getattr(self._dll, name)
             fn.restype, fn.argtypes = res, args
@@ -251,6 +316,29 @@ class Library:
         if _TYPED_API[base][0]:
             return fn(C.byref(params) if params is not None else None, *args)
         return fn(*args)
+
+    # -- consumer side of the contract --------------------------------------------------------
+    def controller_default_params(self) -> ControllerParams:
+        p = ControllerParams()
+        self._check("se3mpc_controller_default_params", self._dll.se3mpc_controller_default_params(C.byref(p)))
+        return p
+
+    def simulator_default_params(self) -> SimulatorParams:
+        p = SimulatorParams()
+        self._check("se3mpc_simulator_default_params", self._dll.se3mpc_simulator_default_params(C.byref(p)))
+        return p
+
+    def controller_reset(self, cp: ControllerParams, B: int, state: int, stream: int) -> None:
+        self._check("se3mpc_controller_reset", self._dll.se3mpc_controller_reset(C.byref(cp), B, state, stream))
+
+    def loop_call(self, base: str, suffix: str, *args) -> None:
+        """se3mpc_control_<suffix> / se3mpc_closed_loop_<suffix>; struct arguments are passed by reference here."""
+        a = [C.byref(x) if isinstance(x, (ControllerParams, SimulatorParams)) else x for x in args]
+        self._check(f"se3mpc_{base}_{suffix}", getattr(self._dll, f"se3mpc_{base}_{suffix}")(*a))
+
+    def loop_status(self, base: str, suffix: str, *args) -> int:
+        a = [C.byref(x) if isinstance(x, (ControllerParams, SimulatorParams)) else x for x in args]
+        return getattr(self._dll, f"se3mpc_{base}_{suffix}")(*a)
 
     # -- voxel map ----------------------------------------------------------------------------
     def voxel(self, name: str, desc: VoxelMapDesc, *args) -> None:

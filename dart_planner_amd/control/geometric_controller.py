@@ -1,145 +1,254 @@
-"""Trajectory -> controller glue of the Planner->Controller contract.
+"""GeometricController -- host-side mirror of the reference's controller, backed by the HIP kernels of
+``dart_planner_amd/csrc/closed_loop.hip``.
 
-The reference's ``GeometricController.compute_control_from_trajectory`` is a stub that returns ``{}``
-(src/dart_planner/control/geometric_controller.py:873-875) and ``compute_body_rate_from_trajectory``
-does not exist, which is why 8 of its 11 contract tests fail.  This module supplies both on top of
-a compact SE(3) geometric tracking controller (position PID + feed-forward -> desired thrust
-vector -> attitude error on SO(3) -> torque), with the reference's public names
-(``compute_control`` :413, ``compute_body_rate_command`` :706, ``config.max_thrust``) and the
-"sitl_optimized" gains of control_config.py:95-111.  Host-side NumPy: the controller consumes the
-planner's output at 400 Hz-1 kHz, it is not part of the accelerated path.
+Same class / method names, arguments and defaults as ``src/dart_planner/control/geometric_controller.py`` of
+DART-Planner ("controller.py" below): ``GeometricControllerConfig`` (:26-77), the tuning profiles of
+``control/control_config.py`` (:52-198), ``compute_control`` (:413-512), ``compute_body_rate_command`` (:706-726),
+``reset`` (:840-860), ``get_performance_metrics``.  Every number is produced on the device (``se3mpc_control_*``,
+``se3mpc_control_plan_*``): the controller's members -- integral, last time stamp, failsafe state, saturation flags --
+live in a 12-word device record; there is no CPU fallback.
+
+The trajectory glue the Planner->Controller contract test calls is a stub in the reference
+(``compute_control_from_trajectory`` returns ``{}``, :873-875) and ``compute_body_rate_from_trajectory`` does not exist.
+Here both are the composition of two reference functions: the plan sampled at ``t`` with
+``OnboardController._interpolate_trajectory`` (control/onboard_controller.py:43-93), then ``compute_control`` with the
+default yaw arguments.  For B drones at once, and for whole closed loops in one launch, use
+``dart_planner_amd.ops.Ops.control`` / ``closed_loop`` directly (see ``dart_planner_amd/control/closed_loop.py``).
 """
 from dataclasses import dataclass, field
 from typing import Optional
 
 import numpy as np
 
+from ..capi import CONTROLLER_STATE_WORDS, ControllerParams
 from ..common.types import BodyRateCommand, ControlCommand, DroneState, Trajectory
 from ..common.units import to_float
 
-_PROFILES = {
-    # name: kp_pos, ki_pos, kd_pos, kp_att, kd_att, max_tilt, max_thrust, min_thrust, max_integral
-    "sitl_optimized": ([20, 20, 25], [1.5, 1.5, 2.0], [10, 10, 12], [18, 18, 8], [7, 7, 3.5], np.pi / 4, 22.0, 0.8, 2.5),
-    "conservative": ([15, 15, 18], [2, 2, 3], [8, 8, 10], [15, 15, 8], [6, 6, 3], np.pi / 6, 20.0, 0.5, 3.0),
-    "precision_tracking": ([18, 18, 22], [2.5, 2.5, 3.5], [12, 12, 14], [22, 22, 10], [8, 8, 4], np.pi / 4, 25.0, 0.8, 2.0),
+# control/control_config.py:52-198: kp_pos, ki_pos, kd_pos, kp_att, kd_att, ff_pos, ff_vel, max_tilt_angle, max_thrust, min_thrust,
+# tracking_error_threshold, velocity_error_threshold, max_integral_pos
+_PI = np.pi
+TUNING_PROFILES = {
+    "conservative": ([15, 15, 18], [2, 2, 3], [8, 8, 10], [15, 15, 8], [6, 6, 3], 1.5, 1.0, _PI / 6, 20.0, 0.5, 1.5, 0.8, 3.0),
+    "aggressive": ([25, 25, 30], [1, 1, 1.5], [12, 12, 15], [20, 20, 10], [8, 8, 4], 2.0, 1.2, _PI / 3, 25.0, 1.0, 0.8, 0.5, 2.0),
+    "sitl_optimized": ([20, 20, 25], [1.5, 1.5, 2.0], [10, 10, 12], [18, 18, 8], [7, 7, 3.5], 1.8, 1.1, _PI / 4, 22.0, 0.8, 1.0, 0.6, 2.5),
+    "precision_tracking": ([18, 18, 22], [2.5, 2.5, 3.5], [12, 12, 14], [22, 22, 10], [8, 8, 4], 2.2, 1.3, _PI / 4, 25.0, 0.8, 0.8, 0.4, 2.0),
+    "enhanced_tracking": ([22, 22, 28], [2.0, 2.0, 2.5], [11, 11, 13], [20, 20, 9], [8, 8, 4], 2.0, 1.2, _PI / 4, 24.0, 0.8, 0.9, 0.5, 2.2),
+    "tracking_optimized": ([21, 21, 26], [1.8, 1.8, 2.2], [10.5, 10.5, 12.5], [18.5, 18.5, 8.2], [7.2, 7.2, 3.6], 1.9, 1.15, _PI / 4, 22.0, 0.8,
+                           0.95, 0.55, 2.3),
+    "original": ([10, 10, 12], [0.5, 0.5, 1.0], [6, 6, 8], [12, 12, 5], [4, 4, 2], 1.2, 0.8, _PI / 3, 20.0, 0.5, 2.0, 1.0, 5.0),
 }
+
+
+def _a(*v):
+    return np.array(v, dtype=float)
 
 
 @dataclass
 class GeometricControllerConfig:
-    kp_pos: np.ndarray = field(default_factory=lambda: np.array([7.0, 7.0, 8.5]))
-    ki_pos: np.ndarray = field(default_factory=lambda: np.array([0.35, 0.35, 0.7]))
-    kd_pos: np.ndarray = field(default_factory=lambda: np.array([4.2, 4.2, 5.6]))
-    kp_att: np.ndarray = field(default_factory=lambda: np.array([9.0, 9.0, 3.75]))
-    kd_att: np.ndarray = field(default_factory=lambda: np.array([3.0, 3.0, 1.5]))
-    inertia: np.ndarray = field(default_factory=lambda: np.array([0.1, 0.1, 0.2]))
-    max_torque_xyz: np.ndarray = field(default_factory=lambda: np.array([2.0, 2.0, 1.0]))
+    """controller.py:26-77, same fields and defaults; mass / gravity / inertia are ``VehicleParams`` (common/vehicle_params.py:19-23),
+    max_torque_xyz the safe default of ``compute_max_torque_xyz`` (:108-115) -- the values the reference instantiates."""
+    kp_pos: np.ndarray = field(default_factory=lambda: _a(7.0, 7.0, 8.5))
+    ki_pos: np.ndarray = field(default_factory=lambda: _a(0.35, 0.35, 0.7))
+    kd_pos: np.ndarray = field(default_factory=lambda: _a(4.2, 4.2, 5.6))
+    kp_att: np.ndarray = field(default_factory=lambda: _a(9.0, 9.0, 3.75))
+    kd_att: np.ndarray = field(default_factory=lambda: _a(3.0, 3.0, 1.5))
+    inertia: np.ndarray = field(default_factory=lambda: _a(0.02, 0.02, 0.04))
+    max_torque_xyz: np.ndarray = field(default_factory=lambda: _a(0.5, 0.5, 0.05))
+    ff_pos: float = 1.2                      # never read by the control law, as in the reference
+    ff_vel: float = 0.8                      # never read
     max_integral_pos: float = 5.0
     max_tilt_angle: float = np.pi / 3
-    mass: float = 1.5
-    gravity: float = 9.81
+    mass: float = 1.0
+    gravity: float = 9.80665
     max_thrust: float = 20.0
     min_thrust: float = 0.5
-
-
-def _rot_from_euler(att):
-    r, p, y = att
-    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
-    return np.array([[cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr],
-                     [sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr],
-                     [-sp, cp * sr, cp * cr]])
-
-
-def _vee(S):
-    return np.array([S[2, 1], S[0, 2], S[1, 0]])
+    tracking_error_threshold: float = 2.0
+    velocity_error_threshold: float = 1.0
+    anti_windup_method: str = "clamping"
+    max_integral_per_axis: np.ndarray = field(default_factory=lambda: _a(2.0, 2.0, 3.0))
+    back_calculation_gain: float = 0.1
+    integral_decay_factor: float = 0.99
+    saturation_threshold: float = 0.95
+    yaw_singularity_threshold: float = 0.1
+    yaw_singularity_fallback_method: str = "skip_yaw"
+    default_heading_yaw: float = 0.0
+    yaw_singularity_warning_threshold: float = 0.3   # logging only in the reference
 
 
 class GeometricController:
-    def __init__(self, config: Optional[GeometricControllerConfig] = None, tuning_profile: str = "sitl_optimized"):
-        self.config = config or GeometricControllerConfig()
-        if tuning_profile in _PROFILES:
-            kp, ki, kd, kpa, kda, tilt, tmax, tmin, imax = _PROFILES[tuning_profile]
-            c = self.config
-            c.kp_pos, c.ki_pos, c.kd_pos = np.array(kp, float), np.array(ki, float), np.array(kd, float)
-            c.kp_att, c.kd_att = np.array(kpa, float), np.array(kda, float)
-            c.max_tilt_angle, c.max_thrust, c.min_thrust, c.max_integral_pos = tilt, tmax, tmin, imax
-        self.tuning_profile = tuning_profile
-        self.reset()
+    """controller.py:79-881 on the device, one drone."""
 
-    def reset(self):
-        self.integral_pos_error = np.zeros(3)
-        self.last_time: Optional[float] = None
+    def __init__(self, config: Optional[GeometricControllerConfig] = None, tuning_profile: str = "sitl_optimized", *,
+                 precision: str = "f64", device=None):
+        if config is None:
+            config = GeometricControllerConfig()
+        if tuning_profile:
+            self._apply_tuning_profile(config, tuning_profile)
+        self.config = config
+        self.tuning_profile_name = tuning_profile
+        self.precision = precision
+        self._device = device
+        self._ops = None
+        self._state = None
+        self.position_errors, self.velocity_errors, self.control_outputs = [], [], []
+        self._thrust_saturation_count = 0
+        self._torque_saturation_count = 0
 
-    # ---- reference geometric_controller.py:413-512 (public signature)
+    def _apply_tuning_profile(self, config: GeometricControllerConfig, profile_name: str) -> None:   # controller.py:140-158
+        prof = TUNING_PROFILES.get(profile_name)
+        if prof is None:
+            return                                          # the reference logs a warning and keeps the defaults
+        kp, ki, kd, kpa, kda, ffp, ffv, tilt, tmax, tmin, terr, verr, imax = prof
+        config.kp_pos, config.ki_pos, config.kd_pos = _a(*kp), _a(*ki), _a(*kd)
+        config.kp_att, config.kd_att = _a(*kpa), _a(*kda)
+        config.ff_pos, config.ff_vel, config.max_tilt_angle = ffp, ffv, tilt
+        config.max_thrust, config.min_thrust, config.max_integral_pos = tmax, tmin, imax
+        config.tracking_error_threshold, config.velocity_error_threshold = terr, verr
+
+    # ------------------------------------------------------------------ device plumbing
+    def _get_ops(self):
+        if self._ops is None:
+            from ..ops import Ops, TorchBackend
+            self._ops = Ops(TorchBackend(self._device))      # raises without a HIP device / built library
+        return self._ops
+
+    def _dev(self, a, kind=None):
+        import torch
+        dt = {"f32": torch.float32, "f64": torch.float64}[kind or self.precision]
+        return torch.as_tensor(np.ascontiguousarray(np.asarray(to_float(a), dtype=float))).to(device=self._get_ops().be.device, dtype=dt)
+
+    def _params(self) -> ControllerParams:
+        return ControllerParams.from_config(self.config)
+
+    def _members(self):
+        if self._state is None:
+            self._state = self._get_ops().controller_state(self._params(), 1)
+        return self._state
+
+    def _state_args(self, current_state: DroneState):
+        z = np.zeros(3)
+        att = np.asarray(to_float(current_state.attitude), float)
+        if att.shape[0] == 4:                                # quaternion attitude (controller.py:791-803): to Euler angles once
+            w, x, y, zq = att
+            att = np.array([np.arctan2(2 * (w * x + y * zq), 1 - 2 * (x * x + y * y)), np.arcsin(np.clip(2 * (w * y - zq * x), -1, 1)),
+                            np.arctan2(2 * (w * zq + x * y), 1 - 2 * (y * y + zq * zq))])
+        row = lambda a: self._dev(np.asarray(to_float(a), float).reshape(1, 3))
+        return (self._dev([float(current_state.timestamp)], "f64"), row(current_state.position), row(current_state.velocity), row(att),
+                row(current_state.angular_velocity if current_state.angular_velocity is not None else z))
+
+    def _bookkeep(self, out):
+        fl = int(out["flags"].cpu()[0])
+        self._thrust_saturation_count += int(bool(fl & 4))
+        self._torque_saturation_count += bin((fl >> 5) & 7).count("1")
+        thrust = float(out["thrust"].cpu()[0])
+        torque = out["torque"].cpu().numpy()[0].astype(float)
+        if not fl & 1:
+            self.control_outputs.append([thrust, *torque])
+        return thrust, torque
+
+    # ------------------------------------------------------------------ controller.py:413-512, :706-726
     def compute_control(self, current_state: DroneState, desired_pos, desired_vel, desired_acc, desired_yaw=0.0,
                         desired_yaw_rate=0.0) -> ControlCommand:
-        c = self.config
-        pos, vel = np.asarray(to_float(current_state.position), float), np.asarray(to_float(current_state.velocity), float)
-        att, omega = np.asarray(to_float(current_state.attitude), float), np.asarray(to_float(current_state.angular_velocity), float)
-        dpos, dvel, dacc = (np.asarray(to_float(a), float) for a in (desired_pos, desired_vel, desired_acc))
-        yaw = float(to_float(desired_yaw))
-        t = current_state.timestamp
-        dt = (t - self.last_time) if self.last_time is not None else 0.0
-        self.last_time = t
-        e_p, e_v = dpos - pos, dvel - vel
-        if 0.0 < dt < 0.1:
-            self.integral_pos_error = np.clip(self.integral_pos_error + e_p * dt, -c.max_integral_pos, c.max_integral_pos)
-        a_cmd = c.kp_pos * e_p + c.kd_pos * e_v + c.ki_pos * self.integral_pos_error + dacc
-        F = c.mass * (a_cmd + np.array([0.0, 0.0, c.gravity]))                   # desired thrust vector, world frame
-        if F[2] < 1e-3:
-            F[2] = 1e-3
-        tilt = np.arctan2(np.linalg.norm(F[:2]), F[2])
-        if tilt > c.max_tilt_angle:                                              # tilt limit: shrink the lateral part
-            F[:2] *= np.tan(c.max_tilt_angle) * F[2] / max(np.linalg.norm(F[:2]), 1e-9)
-        R = _rot_from_euler(att)
-        thrust = float(np.clip(F @ R[:, 2], c.min_thrust, c.max_thrust))
-        b3 = F / np.linalg.norm(F)
-        b1c = np.array([np.cos(yaw), np.sin(yaw), 0.0])
-        b2 = np.cross(b3, b1c)
-        nb2 = np.linalg.norm(b2)
-        b2 = b2 / nb2 if nb2 > 1e-6 else np.array([0.0, 1.0, 0.0])
-        Rd = np.column_stack([np.cross(b2, b3), b2, b3])
-        e_R = 0.5 * _vee(Rd.T @ R - R.T @ Rd)
-        e_w = omega - R.T @ Rd @ np.array([0.0, 0.0, float(to_float(desired_yaw_rate))])
-        torque = -c.kp_att * e_R - c.kd_att * e_w + np.cross(omega, c.inertia * omega)
-        torque = np.clip(torque, -c.max_torque_xyz, c.max_torque_xyz)
+        t, p, v, a, w = self._state_args(current_state)
+        row = lambda x: self._dev(np.asarray(to_float(x), float).reshape(1, 3))
+        out = self._get_ops().control(self._params(), self._members(), t, p, v, a, w, row(desired_pos), row(desired_vel), row(desired_acc),
+                                      self._dev([float(to_float(desired_yaw))]), self._dev([float(to_float(desired_yaw_rate))]))
+        thrust, torque = self._bookkeep(out)
         return ControlCommand(thrust=thrust, torque=torque)
 
-    # ---- reference geometric_controller.py:706-726
-    def compute_body_rate_command(self, current_state, desired_pos, desired_vel, desired_acc, desired_yaw=0.0,
+    def compute_body_rate_command(self, current_state: DroneState, desired_pos, desired_vel, desired_acc, desired_yaw=0.0,
                                   desired_yaw_rate=0.0) -> BodyRateCommand:
-        cmd = self.compute_control(current_state, desired_pos, desired_vel, desired_acc, desired_yaw, desired_yaw_rate)
-        ang_acc = cmd.torque / self.config.inertia
-        rates = np.asarray(to_float(current_state.angular_velocity), float) + ang_acc * 0.001
-        return BodyRateCommand(thrust=float(np.clip(cmd.thrust / self.config.max_thrust, 0.0, 1.0)), body_rates=rates)
+        t, p, v, a, w = self._state_args(current_state)
+        row = lambda x: self._dev(np.asarray(to_float(x), float).reshape(1, 3))
+        out = self._get_ops().control(self._params(), self._members(), t, p, v, a, w, row(desired_pos), row(desired_vel), row(desired_acc),
+                                      self._dev([float(to_float(desired_yaw))]), self._dev([float(to_float(desired_yaw_rate))]),
+                                      want_body_rate=True)
+        self._bookkeep(out)
+        return BodyRateCommand(thrust=float(out["body_thrust"].cpu()[0]), body_rates=out["body_rates"].cpu().numpy()[0].astype(float))
 
-    # ---- the glue the contract test calls (reference: stub at :873-875 / missing)
-    @staticmethod
-    def sample_trajectory(trajectory: Trajectory, t: float):
-        """Linear interpolation of the plan at time t, clamped to its ends; missing arrays -> zeros."""
-        ts = np.asarray(trajectory.timestamps, float)
+    # ------------------------------------------------------------------ the glue of the contract test (reference: stub :873-875 / missing)
+    def _plan_args(self, trajectory: Trajectory):
         P = np.asarray(to_float(trajectory.positions), float)
-        n = len(ts)
-        zeros = np.zeros_like(P)
-        V = zeros if trajectory.velocities is None else np.asarray(to_float(trajectory.velocities), float)
-        A = zeros if trajectory.accelerations is None else np.asarray(to_float(trajectory.accelerations), float)
-        yaws = None if trajectory.yaws is None else np.asarray(to_float(trajectory.yaws), float)
-        yr = None if trajectory.yaw_rates is None else np.asarray(to_float(trajectory.yaw_rates), float)
-        if n == 1 or t <= ts[0]:
-            i, a = 0, 0.0
-        elif t >= ts[-1]:
-            i, a = n - 2 if n > 1 else 0, 1.0
-        else:
-            i = int(np.searchsorted(ts, t, side="right") - 1)
-            a = float((t - ts[i]) / max(ts[i + 1] - ts[i], 1e-12))
-        j = min(i + 1, n - 1)
-        lerp = lambda X: (1 - a) * X[i] + a * X[j]
-        return lerp(P), lerp(V), lerp(A), (0.0 if yaws is None else float(lerp(yaws))), (0.0 if yr is None else float(lerp(yr)))
+        V = None if trajectory.velocities is None else self._dev(np.asarray(to_float(trajectory.velocities), float))
+        A = None if trajectory.accelerations is None else self._dev(np.asarray(to_float(trajectory.accelerations), float))
+        return self._dev(np.asarray(trajectory.timestamps, float), "f64"), self._dev(P), V, A
+
+    def _from_trajectory(self, current_state: DroneState, trajectory: Trajectory, t: float, body_rate: bool, target: bool = False):
+        tt, p, v, a, w = self._state_args(current_state)
+        ts, P, V, A = self._plan_args(trajectory)
+        return self._get_ops().control_plan(self._params(), self._members(), tt, self._dev([float(t)], "f64"), p, v, a, w, ts, P, V, A,
+                                            want_body_rate=body_rate, want_target=target)
 
     def compute_control_from_trajectory(self, current_state: DroneState, trajectory: Trajectory, t: float) -> ControlCommand:
-        p, v, a, yaw, yaw_rate = self.sample_trajectory(trajectory, t)
-        return self.compute_control(current_state, p, v, a, yaw, yaw_rate)
+        thrust, torque = self._bookkeep(self._from_trajectory(current_state, trajectory, t, False))
+        return ControlCommand(thrust=thrust, torque=torque)
 
     def compute_body_rate_from_trajectory(self, current_state: DroneState, trajectory: Trajectory, t: float) -> BodyRateCommand:
-        p, v, a, yaw, yaw_rate = self.sample_trajectory(trajectory, t)
-        return self.compute_body_rate_command(current_state, p, v, a, yaw, yaw_rate)
+        out = self._from_trajectory(current_state, trajectory, t, True)
+        self._bookkeep(out)
+        return BodyRateCommand(thrust=float(out["body_thrust"].cpu()[0]), body_rates=out["body_rates"].cpu().numpy()[0].astype(float))
+
+    def sample_trajectory(self, trajectory: Trajectory, t: float):
+        """The plan sampled at t as the glue sees it (onboard_controller.py:43-93) -> (position, velocity, acceleration, 0.0, 0.0).
+        Evaluated on the device against a scratch copy of the controller members (the controller itself is not advanced)."""
+        keep = self._members().clone()
+        st = DroneState(timestamp=float(t), position=np.zeros(3), velocity=np.zeros(3))
+        tg = self._from_trajectory(st, trajectory, t, False, target=True)["target"].cpu().numpy()[0].astype(float)
+        self._state.copy_(keep)
+        return tg[0:3], tg[3:6], tg[6:9], 0.0, 0.0
+
+    # ------------------------------------------------------------------ members of the reference class, read back from the device record
+    def _word(self, i):
+        return float(self._members().cpu()[0, i])
+
+    @property
+    def integral_vel_error(self) -> np.ndarray:
+        return self._members().cpu().numpy()[0, 0:3].astype(float)
+
+    @property
+    def last_time(self):
+        v = self._word(3)
+        return None if v != v else v
+
+    @property
+    def last_valid_thrust(self) -> float:
+        return self._word(4)
+
+    @property
+    def failsafe_active(self) -> bool:
+        return bool(int(self._word(11)) & 1)
+
+    @property
+    def failsafe_count(self) -> int:
+        return int(self._word(9))
+
+    @property
+    def gain_scale(self) -> float:
+        """0.5 ** (number of failsafe activations): the reference halves kp_pos, kd_pos, kp_att, kd_att in place on every new
+        activation (controller.py:817-821); here ``config`` keeps the profile's values and this factor is applied on the device."""
+        return 0.5 ** int(self._word(10))
+
+    @property
+    def last_thrust_saturated(self) -> bool:
+        return bool(int(self._word(11)) & 2)
+
+    @property
+    def last_torque_saturated(self) -> np.ndarray:
+        f = int(self._word(11))
+        return np.array([bool(f & 4), bool(f & 8), bool(f & 16)])
+
+    def reset(self) -> None:                                 # controller.py:840-860
+        if self._state is not None:
+            self._get_ops().lib.controller_reset(self._params(), 1, self._state.data_ptr(), self._get_ops().be.stream())
+        self.position_errors, self.velocity_errors, self.control_outputs = [], [], []
+        self._thrust_saturation_count = self._torque_saturation_count = 0
+
+    def get_performance_metrics(self) -> dict:               # controller.py:830-838 (the keys that do not need the error logs)
+        return {"anti_windup_method": self.config.anti_windup_method, "integral_magnitude": float(np.linalg.norm(self.integral_vel_error)),
+                "integral_per_axis": self.integral_vel_error.tolist(), "thrust_saturation_count": self._thrust_saturation_count,
+                "torque_saturation_count": self._torque_saturation_count, "failsafe_activations": self.failsafe_count,
+                "yaw_singularity_threshold": self.config.yaw_singularity_threshold,
+                "yaw_singularity_fallback_method": self.config.yaw_singularity_fallback_method}
+
+
+assert CONTROLLER_STATE_WORDS == 12

@@ -1,0 +1,572 @@
+// closed_loop.hip -- the consumer side of the Planner->Controller contract on the device, one drone per lane:
+// plan sample -> geometric controller -> simulator step, repeated `nsteps` times in ONE launch.
+//
+// Reference arithmetic (unit-stripped, reproduced with its quirks; "controller.py" =
+// src/dart_planner/control/geometric_controller.py, "onboard.py" = src/dart_planner/control/onboard_controller.py,
+// "simulator.py" = src/dart_planner/utils/drone_simulator.py):
+//   * plan sample   OnboardController._interpolate_trajectory                onboard.py:43-93
+//   * control law   GeometricController.compute_control + everything it calls  controller.py:413-512, :160-257, :548-658,
+//                   :660-715, :813-828; compute_body_rate_command               controller.py:706-726
+//   * simulator     DroneSimulator.step                                       simulator.py:52-72
+// The glue compute_control_from_trajectory(state, trajectory, t) is a stub in the reference (controller.py:873-875);
+// here it is the composition of the two reference functions above (sampler -> compute_control, yaw = yaw rate = 0).
+//
+// Every drone is an independent, strictly sequential recurrence with ~50 bytes of state, so the kernel is bound by
+// the dependent-instruction latency of one lane (sin/cos/acos/sqrt chains), not by HBM; throughput comes from the number
+// of drones in flight.  The plan is read in place from the solver's outputs (problem layout: P and V blocks of X with
+// stride 9N, accelerations with stride 3N), the state arrays are the [B][3] arrays the next solve reads as p0 / v0, so a
+// receding-horizon Monte-Carlo alternates se3mpc_solve_* and se3mpc_closed_loop_* with no glue kernels in between.
+//
+// Contraction is off in this file: the controller's saturation / singularity / failsafe branches compare against values
+// NumPy computes without FMA; keeping products and sums separately rounded keeps the f64 path on the oracle's side of
+// every branch (transcendental functions still differ by an ulp).
+#pragma clang fp contract(off)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+
+#include "se3mpc_common.hpp"
+
+static_assert(sizeof(se3mpc_controller_params) == 304, "se3mpc_controller_params is part of the C ABI (capi.py mirrors it)");
+static_assert(sizeof(se3mpc_simulator_params) == 56, "se3mpc_simulator_params is part of the C ABI");
+
+namespace se3mpc {
+
+template <typename R>
+struct CtrlDev {
+  R kp_pos[3], ki_pos[3], kd_pos[3], kp_att[3], kd_att[3], inertia[3], max_torque[3], max_int_axis[3];
+  R max_integral_pos, max_tilt, cos_max_tilt, gravity, max_thrust, min_thrust_abs, hover, track_thr, vel_thr, kb, decay, sat_thr,
+      yaw_sing_thr, dh_cos, dh_sin;
+  int anti_windup, fallback;
+};
+
+template <typename R>
+static CtrlDev<R> make_ctrl_dev(const se3mpc_controller_params& p) {
+  CtrlDev<R> c;
+  for (int i = 0; i < 3; ++i) {
+    c.kp_pos[i] = (R)p.kp_pos[i]; c.ki_pos[i] = (R)p.ki_pos[i]; c.kd_pos[i] = (R)p.kd_pos[i];
+    c.kp_att[i] = (R)p.kp_att[i]; c.kd_att[i] = (R)p.kd_att[i]; c.inertia[i] = (R)p.inertia[i];
+    c.max_torque[i] = (R)p.max_torque_xyz[i]; c.max_int_axis[i] = (R)p.max_integral_per_axis[i];
+  }
+  c.max_integral_pos = (R)p.max_integral_pos; c.max_tilt = (R)p.max_tilt_angle; c.cos_max_tilt = (R)std::cos(p.max_tilt_angle);
+  c.gravity = (R)p.gravity; c.max_thrust = (R)p.max_thrust;
+  c.min_thrust_abs = (R)(p.min_thrust * p.mass * p.gravity);              // controller.py:469
+  c.hover = (R)(p.mass * p.gravity);                                       // controller.py:105
+  c.track_thr = (R)p.tracking_error_threshold; c.vel_thr = (R)p.velocity_error_threshold;
+  c.kb = (R)p.back_calculation_gain; c.decay = (R)p.integral_decay_factor; c.sat_thr = (R)p.saturation_threshold;
+  c.yaw_sing_thr = (R)p.yaw_singularity_threshold;
+  c.dh_cos = (R)std::cos(p.default_heading_yaw); c.dh_sin = (R)std::sin(p.default_heading_yaw);
+  c.anti_windup = p.anti_windup_method; c.fallback = p.yaw_fallback_method;
+  return c;
+}
+
+template <typename R>
+struct SimDev {
+  R mass, gravity, inertia[3], max_thrust, max_torque;
+};
+template <typename R>
+static SimDev<R> make_sim_dev(const se3mpc_simulator_params& p) {
+  SimDev<R> s;
+  s.mass = (R)p.mass; s.gravity = (R)p.gravity; s.max_thrust = (R)p.max_thrust; s.max_torque = (R)p.max_torque;
+  for (int i = 0; i < 3; ++i) s.inertia[i] = (R)p.inertia[i];
+  return s;
+}
+
+// The mutable members of GeometricController that compute_control reads or writes (controller.py:87-105), in registers.
+// In memory: double[SE3MPC_CONTROLLER_STATE_WORDS] per drone (include/se3mpc.h).
+template <typename R>
+struct CtrlRegs {
+  R integral[3];
+  double last_time;          // NaN = None
+  R last_valid_thrust, unsat_thrust, unsat_torque[3];
+  int failsafe_count, halvings, flags;   // flags: 1 failsafe_active, 2 last_thrust_saturated, 4/8/16 last_torque_saturated x/y/z
+};
+
+template <typename R>
+__device__ __forceinline__ CtrlRegs<R> load_ctrl(const double* __restrict__ s) {
+  CtrlRegs<R> r;
+  for (int i = 0; i < 3; ++i) { r.integral[i] = (R)s[i]; r.unsat_torque[i] = (R)s[6 + i]; }
+  r.last_time = s[3]; r.last_valid_thrust = (R)s[4]; r.unsat_thrust = (R)s[5];
+  r.failsafe_count = (int)s[9]; r.halvings = (int)s[10]; r.flags = (int)s[11];
+  return r;
+}
+template <typename R>
+__device__ __forceinline__ void store_ctrl(double* __restrict__ s, const CtrlRegs<R>& r) {
+  for (int i = 0; i < 3; ++i) { s[i] = (double)r.integral[i]; s[6 + i] = (double)r.unsat_torque[i]; }
+  s[3] = r.last_time; s[4] = (double)r.last_valid_thrust; s[5] = (double)r.unsat_thrust;
+  s[9] = (double)r.failsafe_count; s[10] = (double)r.halvings; s[11] = (double)r.flags;
+}
+
+template <typename R>
+__device__ __forceinline__ R norm3(const R v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+template <typename R>
+__device__ __forceinline__ R sign_of(R v) { return v > (R)0 ? (R)1 : (v < (R)0 ? (R)-1 : v); }   // np.sign (NaN stays NaN)
+template <typename R>
+__device__ __forceinline__ void cross3(const R a[3], const R b[3], R o[3]) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+// _get_failsafe_command (controller.py:813-828)
+template <typename R>
+__device__ __forceinline__ void enter_failsafe(CtrlRegs<R>& s) {
+  if (!(s.flags & 1)) {
+    s.halvings += 1;                                                     // :817-821 gains * 0.5
+    s.integral[0] = s.integral[1] = s.integral[2] = (R)0;                // :823
+    s.failsafe_count += 1;                                               // :825
+  }
+  s.flags |= 1;                                                          // :827
+}
+
+// Output flags of one control call.
+enum { CF_FAILSAFE = 1, CF_BAD_DT = 2, CF_THRUST_SAT = 4, CF_SINGULAR = 8, CF_TILT = 16, CF_TORQUE_SAT_X = 32 };
+
+// GeometricController.compute_control (controller.py:413-512) for one drone.
+template <typename R>
+__device__ void control_step(const CtrlDev<R>& c, CtrlRegs<R>& s, double t, const R pos[3], const R vel[3], const R att[3],
+                             const R omega[3], const R dpos[3], const R dvel[3], const R dacc[3], R yaw_des, R yaw_rate_des,
+                             R& thrust_out, R torque_out[3], int& out_flags) {
+  out_flags = 0;
+  const double dt_d = (s.last_time != s.last_time) ? 0.001 : t - s.last_time;   // :440
+  s.last_time = t;                                                               // :441
+  if (dt_d <= 0.0 || dt_d > 0.1) {                                               // :442-443
+    enter_failsafe(s);
+    thrust_out = s.last_valid_thrust; torque_out[0] = torque_out[1] = torque_out[2] = (R)0;
+    out_flags = CF_FAILSAFE | CF_BAD_DT;
+    return;
+  }
+  const R dt = (R)dt_d;
+  const R scale = (R)ldexp(1.0, -s.halvings);                                    // 0.5 ** halvings, exact
+  R pe[3], ve[3], tvw[3];
+  for (int i = 0; i < 3; ++i) { pe[i] = dpos[i] - pos[i]; ve[i] = dvel[i] - vel[i]; }   // :445-446
+  const R pen = norm3(pe), ven = norm3(ve);
+  for (int i = 0; i < 3; ++i) {
+    const R acc_pid = ((c.kp_pos[i] * scale) * pe[i] + (c.kd_pos[i] * scale) * ve[i]) + c.ki_pos[i] * s.integral[i];   // :453-457
+    tvw[i] = dacc[i] + acc_pid;                                                  // :458
+  }
+  tvw[2] = tvw[2] + c.gravity;                                                   // :461 acc_des - (0, 0, -g)
+  R tm = norm3(tvw);                                                             // :462
+  s.unsat_thrust = tm;                                                           // :465
+  bool thrust_sat = false;
+  if (tm > c.max_thrust) { tm = c.max_thrust; thrust_sat = true; }               // :470-475
+  else if (tm < c.min_thrust_abs) { tm = c.min_thrust_abs; thrust_sat = true; }
+  s.flags = (s.flags & ~2) | (thrust_sat ? 2 : 0);                               // :477
+  if (thrust_sat) out_flags |= CF_THRUST_SAT;
+  // ---- _update_integral_error (:548-578); the torque saturation flags are still the previous call's
+  {
+    R upd[3];
+    for (int i = 0; i < 3; ++i) upd[i] = ve[i] * dt;
+    if (c.anti_windup == 0) {                                                    // clamping (:580-598)
+      if (thrust_sat) for (int i = 0; i < 3; ++i) upd[i] = upd[i] * (R)0.1;
+      for (int i = 0; i < 3; ++i) if (s.flags & (4 << i)) upd[i] = upd[i] * (R)0.1;
+    } else if (c.anti_windup == 1) {                                             // back-calculation (:600-623)
+      if (thrust_sat) {
+        const R fb = (s.unsat_thrust - c.max_thrust) * c.kb;
+        upd[0] = upd[0] - fb * (R)0.33; upd[1] = upd[1] - fb * (R)0.33; upd[2] = upd[2] - fb * (R)0.34;
+      }
+      for (int i = 0; i < 3; ++i)
+        if (s.flags & (4 << i)) upd[i] = upd[i] - ((s.unsat_torque[i] - c.max_torque[i]) * c.kb) * (R)0.5;
+    }
+    R I[3];
+    for (int i = 0; i < 3; ++i) {
+      I[i] = s.integral[i] + upd[i];                                             // :574
+      if (fabs(I[i]) > c.max_int_axis[i]) I[i] = sign_of(I[i]) * c.max_int_axis[i];   // :630-632
+    }
+    const R mag = norm3(I);
+    if (mag > c.max_integral_pos) { const R f = c.max_integral_pos / mag; for (int i = 0; i < 3; ++i) I[i] = I[i] * f; }   // :635-637
+    for (int i = 0; i < 3; ++i) {
+      if (fabs(I[i]) > c.max_int_axis[i] * c.sat_thr) I[i] = I[i] * c.decay;     // :640-643
+      s.integral[i] = I[i];
+    }
+  }
+  // ---- _check_tracking_performance (:650-658)
+  if (pen > c.track_thr && ven > c.vel_thr) s.failsafe_count += 1;
+  else s.failsafe_count = s.failsafe_count > 1 ? s.failsafe_count - 1 : 0;
+  if (s.failsafe_count > 100) {                                                  // :485-486
+    enter_failsafe(s);
+    thrust_out = s.last_valid_thrust; torque_out[0] = torque_out[1] = torque_out[2] = (R)0;
+    out_flags |= CF_FAILSAFE;
+    return;
+  }
+  // ---- desired thrust direction (:487-496): divided by the SATURATED magnitude, then the tilt limit
+  R b3[3];
+  if (tm > (R)1e-6) { b3[0] = tvw[0] / tm; b3[1] = tvw[1] / tm; b3[2] = tvw[2] / tm; }
+  else { b3[0] = (R)0; b3[1] = (R)0; b3[2] = (R)1; }
+  const R tilt = acos(fmin(fmax(b3[2], (R)-1), (R)1));
+  if (tilt > c.max_tilt) {
+    const R sf = c.cos_max_tilt / b3[2];
+    b3[0] = b3[0] * sf; b3[1] = b3[1] * sf; b3[2] = c.cos_max_tilt;
+    const R n = norm3(b3);
+    b3[0] = b3[0] / n; b3[1] = b3[1] / n; b3[2] = b3[2] / n;
+    out_flags |= CF_TILT;
+  }
+  // ---- _geometric_attitude_control (:660-715)
+  const R cr = cos(att[0]), sr = sin(att[0]), cp = cos(att[1]), sp = sin(att[1]), cy = cos(att[2]), sy = sin(att[2]);
+  const R Rm[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},   // :774-789
+                      {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
+                      {-sp, cp * sr, cp * cr}};
+  const R yv[3] = {cos(yaw_des), sin(yaw_des), (R)0};                             // :665
+  const R n3 = norm3(b3);
+  const R b3n[3] = {b3[0] / n3, b3[1] / n3, b3[2] / n3};                          // :667
+  const R cos_angle = fabs(yv[0] * b3n[0] + yv[1] * b3n[1] + yv[2] * b3n[2]);     // :174
+  R b1[3], b2[3];
+  if (cos_angle >= c.yaw_sing_thr) {                                              // :177, :191-257
+    out_flags |= CF_SINGULAR;
+    R proj[3] = {(R)1 - b3n[0] * b3n[0], (R)0 - b3n[0] * b3n[1], (R)0 - b3n[0] * b3n[2]};   // [1,0,0] - ([1,0,0].b3) b3
+    const R np_ = norm3(proj);
+    proj[0] = proj[0] / np_; proj[1] = proj[1] / np_; proj[2] = proj[2] / np_;
+    if (c.fallback == 1 || c.fallback == 2) {                                     // default_heading / maintain_current
+      const R hv[3] = {c.fallback == 1 ? c.dh_cos : cy, c.fallback == 1 ? c.dh_sin : sy, (R)0};
+      R cx[3];
+      cross3(hv, b3n, cx);
+      const R nc = norm3(cx);
+      if (nc > (R)1e-6) { b1[0] = cx[0] / nc; b1[1] = cx[1] / nc; b1[2] = cx[2] / nc; }
+      else { b1[0] = proj[0]; b1[1] = proj[1]; b1[2] = proj[2]; }
+    } else if (c.fallback != 0 || fabs(b3n[2]) < (R)0.99) {                       // skip_yaw (:212-217); unknown methods (:248-252)
+      b1[0] = proj[0]; b1[1] = proj[1]; b1[2] = proj[2];
+    } else {                                                                      // :218-220
+      b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0;
+    }
+  } else {                                                                        // :680-688
+    cross3(yv, b3n, b1);
+    const R n1 = norm3(b1);
+    if (n1 > (R)1e-6) { b1[0] = b1[0] / n1; b1[1] = b1[1] / n1; b1[2] = b1[2] / n1; }
+    else { b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0; }
+  }
+  cross3(b3n, b1, b2);                                                            // :255 / :689
+  const R Rd[3][3] = {{b1[0], b2[0], b3n[0]}, {b1[1], b2[1], b3n[1]}, {b1[2], b2[2], b3n[2]}};   // column_stack
+  // eR = 0.5 vee(Rd^T R - R^T Rd) (:692): vee(M) = (M21, M02, M10)
+  auto dtr = [&](const R A_[3][3], const R B_[3][3], int i, int j) { return (A_[0][i] * B_[0][j] + A_[1][i] * B_[1][j]) + A_[2][i] * B_[2][j]; };
+  const R eR[3] = {(R)0.5 * (dtr(Rd, Rm, 2, 1) - dtr(Rm, Rd, 2, 1)), (R)0.5 * (dtr(Rd, Rm, 0, 2) - dtr(Rm, Rd, 0, 2)),
+                   (R)0.5 * (dtr(Rd, Rm, 1, 0) - dtr(Rm, Rd, 1, 0))};
+  const R eO[3] = {omega[0], omega[1], omega[2] - yaw_rate_des};                  // :693-695
+  const R Iw[3] = {c.inertia[0] * omega[0], c.inertia[1] * omega[1], c.inertia[2] * omega[2]};
+  R cor[3];
+  cross3(omega, Iw, cor);                                                         // :700
+  int tsat = 0;
+  for (int i = 0; i < 3; ++i) {
+    R tq = (-(c.kp_att[i] * scale) * eR[i] - (c.kd_att[i] * scale) * eO[i]) + cor[i];   // :701
+    s.unsat_torque[i] = tq;                                                       // :704
+    if (fabs(tq) > c.max_torque[i]) { tq = sign_of(tq) * c.max_torque[i]; tsat |= (4 << i); }   // :708-711
+    torque_out[i] = tq;
+  }
+  s.flags = (s.flags & ~(4 | 8 | 16)) | tsat;                                     // :713
+  out_flags |= (tsat >> 2) * CF_TORQUE_SAT_X;
+  s.last_valid_thrust = tm;                                                       // :505
+  s.flags &= ~1;                                                                  // :506
+  s.failsafe_count = 0;                                                           // :507
+  thrust_out = tm;
+}
+
+// OnboardController._interpolate_trajectory (onboard.py:43-93).  ts: N timestamps (double); P, V, A: [N][3] rows (V, A may be null).
+template <typename R>
+__device__ __forceinline__ void sample_plan(double t, int N, const double* __restrict__ ts, const R* __restrict__ P, const R* __restrict__ V,
+                                            const R* __restrict__ A, R tp[3], R tv[3], R ta[3]) {
+  int idx = 0;                                                                    // np.searchsorted(ts, t): first i with ts[i] >= t
+  while (idx < N && ts[idx] < t) ++idx;
+  int i1, i2;
+  R f = (R)0;
+  if (idx == 0) { i1 = i2 = 0; }                                                  // :51-63
+  else if (idx >= N) { i1 = i2 = N - 1; }                                         // :64-75
+  else {
+    i1 = idx - 1; i2 = idx;
+    f = (R)((t - ts[i1]) / (ts[i2] - ts[i1]));                                    // :80
+  }
+  for (int a = 0; a < 3; ++a) {
+    const R p1 = P[3 * i1 + a], p2 = P[3 * i2 + a];
+    tp[a] = (i1 == i2) ? p1 : p1 + f * (p2 - p1);                                 // :81
+    tv[a] = (R)0; ta[a] = (R)0;
+    if (V != nullptr) { const R v1 = V[3 * i1 + a], v2 = V[3 * i2 + a]; tv[a] = (i1 == i2) ? v1 : v1 + f * (v2 - v1); }   // :83-86
+    if (A != nullptr) { const R a1 = A[3 * i1 + a], a2 = A[3 * i2 + a]; ta[a] = (i1 == i2) ? a1 : a1 + f * (a2 - a1); }   // :88-91
+  }
+}
+
+// DroneSimulator.step (simulator.py:52-72)
+template <typename R>
+__device__ __forceinline__ void simulator_step(const SimDev<R>& m, R pos[3], R vel[3], R att[3], R omega[3], double& t, R thrust,
+                                               const R torque[3], R dt, double dt_d, const R wind[3]) {
+  thrust = fmin(fmax(thrust, (R)0), m.max_thrust);                                // :54
+  for (int i = 0; i < 3; ++i) {
+    const R tq = fmin(fmax(torque[i], -m.max_torque), m.max_torque);              // :55
+    const R wind_accel = wind[i] / m.mass;                                        // :57
+    const R acc = ((i == 2 ? -m.gravity : (R)0) + (i == 2 ? thrust / m.mass : (R)0)) + wind_accel;   // :59
+    vel[i] = vel[i] + acc * dt;                                                   // :60
+    pos[i] = pos[i] + vel[i] * dt;                                                // :61
+    const R ang_acc = tq / m.inertia[i];                                          // :63
+    omega[i] = omega[i] + ang_acc * dt;                                           // :64
+    att[i] = att[i] + omega[i] * dt;                                              // :65
+  }
+  t = t + dt_d;                                                                   // :67
+}
+
+// ---- one control call per drone (compute_control / compute_body_rate_command for B drones)
+template <typename R>
+__global__ void __launch_bounds__(64)
+control_kernel(CtrlDev<R> c, int B, const double* __restrict__ time, const R* __restrict__ pos, const R* __restrict__ vel,
+               const R* __restrict__ att, const R* __restrict__ omega, const R* __restrict__ dpos, const R* __restrict__ dvel,
+               const R* __restrict__ dacc, const R* __restrict__ yaw, const R* __restrict__ yaw_rate, double* __restrict__ state,
+               R* __restrict__ thrust, R* __restrict__ torque, R* __restrict__ body_thrust, R* __restrict__ body_rates,
+               int32_t* __restrict__ flags, const double* __restrict__ sample_time, int N, const double* __restrict__ timestamps,
+               long long ts_stride, const R* __restrict__ P, long long strideP, const R* __restrict__ V, long long strideV,
+               const R* __restrict__ A, long long strideA, R* __restrict__ target) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  CtrlRegs<R> s = load_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS);
+  R p[3], v[3], a[3], w[3], dp[3], dv[3], da[3];
+  for (int i = 0; i < 3; ++i) { p[i] = pos[3 * b + i]; v[i] = vel[3 * b + i]; a[i] = att[3 * b + i]; w[i] = omega[3 * b + i]; }
+  if (sample_time != nullptr) {                       // compute_control_from_trajectory: the target is the plan sampled at sample_time
+    sample_plan<R>(sample_time[b], N, timestamps + (size_t)b * ts_stride, P + (size_t)b * strideP,
+                   V != nullptr ? V + (size_t)b * strideV : nullptr, A != nullptr ? A + (size_t)b * strideA : nullptr, dp, dv, da);
+    if (target != nullptr) for (int i = 0; i < 3; ++i) { target[9 * b + i] = dp[i]; target[9 * b + 3 + i] = dv[i]; target[9 * b + 6 + i] = da[i]; }
+  } else {
+    for (int i = 0; i < 3; ++i) { dp[i] = dpos[3 * b + i]; dv[i] = dvel[3 * b + i]; da[i] = dacc != nullptr ? dacc[3 * b + i] : (R)0; }
+  }
+  R th, tq[3];
+  int fl;
+  control_step<R>(c, s, time[b], p, v, a, w, dp, dv, da, yaw != nullptr ? yaw[b] : (R)0, yaw_rate != nullptr ? yaw_rate[b] : (R)0, th, tq, fl);
+  store_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS, s);
+  if (thrust != nullptr) thrust[b] = th;
+  if (torque != nullptr) for (int i = 0; i < 3; ++i) torque[3 * b + i] = tq[i];
+  if (body_thrust != nullptr) body_thrust[b] = fmin(fmax(th / c.max_thrust, (R)0), (R)1);   // controller.py:721
+  if (body_rates != nullptr) {
+    const R inr[3] = {(R)0.1, (R)0.1, (R)0.2};                                    // controller.py:717 (its own inertia, not the config's)
+    for (int i = 0; i < 3; ++i) body_rates[3 * b + i] = w[i] + (tq[i] / inr[i]) * (R)0.001;   // :718-720
+  }
+  if (flags != nullptr) flags[b] = fl;
+}
+
+// ---- the closed loop: nsteps x (sample, control, simulate) per drone in one launch
+template <typename R>
+__global__ void __launch_bounds__(64)
+closed_loop_kernel(CtrlDev<R> c, SimDev<R> m, int B, int nsteps, double sim_dt, int N, const double* __restrict__ timestamps,
+                   long long ts_stride, const R* __restrict__ P, long long strideP, const R* __restrict__ V, long long strideV,
+                   const R* __restrict__ A, long long strideA, double* __restrict__ time, R* __restrict__ pos, R* __restrict__ vel,
+                   R* __restrict__ att, R* __restrict__ omega, double* __restrict__ state, const R* __restrict__ wind,
+                   long long wind_stride, int gust_step, R gx, R gy, R gz, int stop_at_plan_end, R* __restrict__ log_state,
+                   R* __restrict__ log_cmd, double* __restrict__ log_time, int32_t* __restrict__ steps_taken) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  CtrlRegs<R> s = load_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS);
+  R p[3], v[3], a[3], w[3], wd[3] = {(R)0, (R)0, (R)0};
+  for (int i = 0; i < 3; ++i) {
+    p[i] = pos[3 * b + i]; v[i] = vel[3 * b + i]; a[i] = att[3 * b + i]; w[i] = omega[3 * b + i];
+    if (wind != nullptr) wd[i] = wind[(size_t)b * wind_stride + i];
+  }
+  double t = time[b];
+  const double* ts = timestamps + (size_t)b * ts_stride;
+  const R* Pb = P + (size_t)b * strideP;
+  const R* Vb = V != nullptr ? V + (size_t)b * strideV : nullptr;
+  const R* Ab = A != nullptr ? A + (size_t)b * strideA : nullptr;
+  const double ts_last = ts[N - 1];
+  const R dt = (R)sim_dt;
+  int taken = 0;
+  bool active = true;
+  for (int step = 0; step < nsteps; ++step) {
+    if (stop_at_plan_end && t > ts_last) active = false;                          // contract tests :130-131 / :263-264 (`break`)
+    if (log_state != nullptr) {
+      R* ls = log_state + ((size_t)step * B + b) * 12;
+      for (int i = 0; i < 3; ++i) { ls[i] = p[i]; ls[3 + i] = v[i]; ls[6 + i] = a[i]; ls[9 + i] = w[i]; }
+    }
+    if (log_time != nullptr) log_time[(size_t)step * B + b] = t;
+    R th = (R)NAN, tq[3] = {(R)NAN, (R)NAN, (R)NAN};
+    if (active) {
+      R tp[3], tv[3], ta[3];
+      sample_plan<R>(t, N, ts, Pb, Vb, Ab, tp, tv, ta);
+      int fl;
+      control_step<R>(c, s, t, p, v, a, w, tp, tv, ta, (R)0, (R)0, th, tq, fl);
+      if (step == gust_step) { wd[0] = gx; wd[1] = gy; wd[2] = gz; }              // the gust of contract test :293-296
+      simulator_step<R>(m, p, v, a, w, t, th, tq, dt, sim_dt, wd);
+      ++taken;
+    }
+    if (log_cmd != nullptr) {
+      R* lc = log_cmd + ((size_t)step * B + b) * 4;
+      lc[0] = th; lc[1] = tq[0]; lc[2] = tq[1]; lc[3] = tq[2];
+    }
+  }
+  for (int i = 0; i < 3; ++i) { pos[3 * b + i] = p[i]; vel[3 * b + i] = v[i]; att[3 * b + i] = a[i]; omega[3 * b + i] = w[i]; }
+  time[b] = t;
+  store_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS, s);
+  if (steps_taken != nullptr) steps_taken[b] = taken;
+}
+
+// ---- DroneSimulator.step alone (simulator.py:52-72) for B drones with given commands
+template <typename R>
+__global__ void __launch_bounds__(64)
+simulator_step_kernel(SimDev<R> m, int B, double dt_d, const R* __restrict__ thrust, const R* __restrict__ torque, const R* __restrict__ wind,
+                      long long wind_stride, double* __restrict__ time, R* __restrict__ pos, R* __restrict__ vel, R* __restrict__ att,
+                      R* __restrict__ omega) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  R p[3], v[3], a[3], w[3], tq[3], wd[3];
+  for (int i = 0; i < 3; ++i) {
+    p[i] = pos[3 * b + i]; v[i] = vel[3 * b + i]; a[i] = att[3 * b + i]; w[i] = omega[3 * b + i]; tq[i] = torque[3 * b + i];
+    wd[i] = wind != nullptr ? wind[(size_t)b * wind_stride + i] : (R)0;
+  }
+  double t = time[b];
+  simulator_step<R>(m, p, v, a, w, t, thrust[b], tq, (R)dt_d, dt_d, wd);
+  for (int i = 0; i < 3; ++i) { pos[3 * b + i] = p[i]; vel[3 * b + i] = v[i]; att[3 * b + i] = a[i]; omega[3 * b + i] = w[i]; }
+  time[b] = t;
+}
+
+__global__ void __launch_bounds__(64)
+controller_reset_kernel(int B, double hover, double* __restrict__ state) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double* s = state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS;
+  for (int i = 0; i < SE3MPC_CONTROLLER_STATE_WORDS; ++i) s[i] = 0.0;
+  s[3] = __builtin_nan("");                                                      // last_time = None (controller.py:92)
+  s[4] = hover;                                                                   // last_valid_thrust = mass * gravity (:105)
+}
+
+static int check_controller_params(const se3mpc_controller_params* p) {
+  if (p == nullptr) return SE3MPC_ERR_NULL;
+  const double* d = reinterpret_cast<const double*>(p);
+  for (int i = 0; i < 37; ++i)
+    if (!std::isfinite(d[i])) return SE3MPC_ERR_PARAM;
+  if (!(p->mass > 0.0) || p->anti_windup_method < 0 || p->anti_windup_method > 2 || p->yaw_fallback_method < 0 || p->yaw_fallback_method > 3)
+    return SE3MPC_ERR_PARAM;
+  return SE3MPC_OK;
+}
+
+template <typename R>
+int control_impl(const se3mpc_controller_params* cp, int B, const double* time, const R* pos, const R* vel, const R* att, const R* omega,
+                 const R* dpos, const R* dvel, const R* dacc, const R* yaw, const R* yaw_rate, double* state, R* thrust, R* torque,
+                 R* body_thrust, R* body_rates, int32_t* flags, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!time || !pos || !vel || !att || !omega || !dpos || !dvel || !state) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(control_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), B, time, pos, vel,
+                     att, omega, dpos, dvel, dacc, yaw, yaw_rate, state, thrust, torque, body_thrust, body_rates, flags,
+                     (const double*)nullptr, 0, (const double*)nullptr, 0LL, (const R*)nullptr, 0LL, (const R*)nullptr, 0LL, (const R*)nullptr, 0LL,
+                     (R*)nullptr);
+  return launch_status("se3mpc_control");
+}
+
+template <typename R>
+int control_plan_impl(const se3mpc_controller_params* cp, int B, const double* time, const double* sample_time, const R* pos, const R* vel,
+                      const R* att, const R* omega, int N, const double* timestamps, long long ts_stride, const R* P, long long strideP,
+                      const R* V, long long strideV, const R* A, long long strideA, double* state, R* thrust, R* torque, R* body_thrust,
+                      R* body_rates, int32_t* flags, R* target, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  if (B < 0 || N < 1 || N > 4096 || ts_stride < 0 || strideP < 0 || strideV < 0 || strideA < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!time || !sample_time || !pos || !vel || !att || !omega || !timestamps || !P || !state) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(control_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), B, time, pos, vel,
+                     att, omega, (const R*)nullptr, (const R*)nullptr, (const R*)nullptr, (const R*)nullptr, (const R*)nullptr, state, thrust,
+                     torque, body_thrust, body_rates, flags, sample_time, N, timestamps, ts_stride, P, strideP, V, strideV, A, strideA, target);
+  return launch_status("se3mpc_control_plan");
+}
+
+static int check_simulator_params(const se3mpc_simulator_params* sp) {
+  if (sp == nullptr) return SE3MPC_ERR_NULL;
+  if (!(sp->mass > 0.0) || !std::isfinite(sp->gravity) || !(sp->inertia[0] > 0.0) || !(sp->inertia[1] > 0.0) || !(sp->inertia[2] > 0.0) ||
+      !std::isfinite(sp->max_thrust) || !std::isfinite(sp->max_torque))
+    return SE3MPC_ERR_PARAM;
+  return SE3MPC_OK;
+}
+
+template <typename R>
+int simulator_step_impl(const se3mpc_simulator_params* sp, int B, double dt, const R* thrust, const R* torque, const R* wind,
+                        long long wind_stride, double* time, R* pos, R* vel, R* att, R* omega, void* stream) {
+  int rc = check_simulator_params(sp);
+  if (rc) return rc;
+  if (!std::isfinite(dt)) return SE3MPC_ERR_PARAM;
+  if (B < 0 || wind_stride < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!thrust || !torque || !time || !pos || !vel || !att || !omega) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(simulator_step_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_sim_dev<R>(*sp), B, dt, thrust,
+                     torque, wind, wind_stride, time, pos, vel, att, omega);
+  return launch_status("se3mpc_simulator_step");
+}
+
+template <typename R>
+int closed_loop_impl(const se3mpc_controller_params* cp, const se3mpc_simulator_params* sp, int B, int nsteps, double sim_dt, int N,
+                     const double* timestamps, long long ts_stride, const R* P, long long strideP, const R* V, long long strideV,
+                     const R* A, long long strideA, double* time, R* pos, R* vel, R* att, R* omega, double* state, const R* wind,
+                     long long wind_stride, int gust_step, const double* gust_wind, int stop_at_plan_end, R* log_state, R* log_cmd,
+                     double* log_time, int32_t* steps_taken, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  rc = check_simulator_params(sp);
+  if (rc) return rc;
+  if (!std::isfinite(sim_dt)) return SE3MPC_ERR_PARAM;
+  if (B < 0 || nsteps < 0 || N < 1 || N > 4096 || ts_stride < 0 || strideP < 0 || strideV < 0 || strideA < 0 || wind_stride < 0)
+    return SE3MPC_ERR_SHAPE;
+  if (B == 0 || nsteps == 0) return SE3MPC_OK;
+  if (!timestamps || !P || !time || !pos || !vel || !att || !omega || !state || (gust_step >= 0 && !gust_wind)) return SE3MPC_ERR_NULL;
+  const R gx = gust_step >= 0 ? (R)gust_wind[0] : (R)0, gy = gust_step >= 0 ? (R)gust_wind[1] : (R)0, gz = gust_step >= 0 ? (R)gust_wind[2] : (R)0;
+  hipLaunchKernelGGL(closed_loop_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), make_sim_dev<R>(*sp),
+                     B, nsteps, sim_dt, N, timestamps, ts_stride, P, strideP, V, strideV, A, strideA, time, pos, vel, att, omega, state, wind,
+                     wind_stride, gust_step, gx, gy, gz, stop_at_plan_end, log_state, log_cmd, log_time, steps_taken);
+  return launch_status("se3mpc_closed_loop");
+}
+
+}  // namespace se3mpc
+
+using namespace se3mpc;
+
+extern "C" int se3mpc_controller_default_params(se3mpc_controller_params* out) {
+  if (out == nullptr) return SE3MPC_ERR_NULL;
+  // GeometricControllerConfig (controller.py:26-77) after _apply_tuning_profile("sitl_optimized") (:140-158, control_config.py:95-111);
+  // mass / gravity / inertia: VehicleParams (common/vehicle_params.py:19-23); max_torque_xyz: compute_max_torque_xyz's safe default (:108-115)
+  const se3mpc_controller_params d = {{20.0, 20.0, 25.0}, {1.5, 1.5, 2.0}, {10.0, 10.0, 12.0}, {18.0, 18.0, 8.0}, {7.0, 7.0, 3.5},
+                                      {0.02, 0.02, 0.04}, {0.5, 0.5, 0.05}, {2.0, 2.0, 3.0},
+                                      2.5, M_PI / 4.0, 1.0, 9.80665, 22.0, 0.8, 1.0, 0.6, 0.1, 0.99, 0.95, 0.1, 0.0, 0, 0};
+  *out = d;
+  return SE3MPC_OK;
+}
+
+extern "C" int se3mpc_simulator_default_params(se3mpc_simulator_params* out) {
+  if (out == nullptr) return SE3MPC_ERR_NULL;
+  const se3mpc_simulator_params d = {1.5, 9.81, {0.1, 0.1, 0.2}, 20.0, 10.0};     // simulator.py:41-50
+  *out = d;
+  return SE3MPC_OK;
+}
+
+extern "C" int se3mpc_controller_reset(const se3mpc_controller_params* cp, int B, double* state, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!state) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(controller_reset_kernel, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, B, cp->mass * cp->gravity, state);
+  return launch_status("se3mpc_controller_reset");
+}
+
+#define SE3MPC_DEFINE_LOOP_API(SUF, R)                                                                                      \
+  extern "C" int se3mpc_control_##SUF(const se3mpc_controller_params* cp, int B, const double* time, const R* pos, const R* vel, \
+                                      const R* att, const R* omega, const R* dpos, const R* dvel, const R* dacc, const R* yaw, \
+                                      const R* yaw_rate, double* state, R* thrust, R* torque, R* body_thrust, R* body_rates,  \
+                                      int32_t* flags, void* stream) {                                                       \
+    return control_impl<R>(cp, B, time, pos, vel, att, omega, dpos, dvel, dacc, yaw, yaw_rate, state, thrust, torque,       \
+                           body_thrust, body_rates, flags, stream);                                                        \
+  }                                                                                                                         \
+  extern "C" int se3mpc_control_plan_##SUF(const se3mpc_controller_params* cp, int B, const double* time, const double* sample_time, \
+                                           const R* pos, const R* vel, const R* att, const R* omega, int N, const double* timestamps, \
+                                           long long ts_stride, const R* P, long long strideP, const R* V, long long strideV,   \
+                                           const R* A, long long strideA, double* state, R* thrust, R* torque, R* body_thrust,  \
+                                           R* body_rates, int32_t* flags, R* target, void* stream) {                           \
+    return control_plan_impl<R>(cp, B, time, sample_time, pos, vel, att, omega, N, timestamps, ts_stride, P, strideP, V, strideV, A, \
+                                strideA, state, thrust, torque, body_thrust, body_rates, flags, target, stream);               \
+  }                                                                                                                         \
+  extern "C" int se3mpc_simulator_step_##SUF(const se3mpc_simulator_params* sp, int B, double dt, const R* thrust, const R* torque, \
+                                             const R* wind, long long wind_stride, double* time, R* pos, R* vel, R* att, R* omega, \
+                                             void* stream) {                                                                \
+    return simulator_step_impl<R>(sp, B, dt, thrust, torque, wind, wind_stride, time, pos, vel, att, omega, stream);         \
+  }                                                                                                                         \
+  extern "C" int se3mpc_closed_loop_##SUF(const se3mpc_controller_params* cp, const se3mpc_simulator_params* sp, int B,      \
+                                          int nsteps, double sim_dt, int N, const double* timestamps, long long ts_stride,   \
+                                          const R* P, long long strideP, const R* V, long long strideV, const R* A,          \
+                                          long long strideA, double* time, R* pos, R* vel, R* att, R* omega, double* state,  \
+                                          const R* wind, long long wind_stride, int gust_step, const double* gust_wind,      \
+                                          int stop_at_plan_end, R* log_state, R* log_cmd, double* log_time,                  \
+                                          int32_t* steps_taken, void* stream) {                                             \
+    return closed_loop_impl<R>(cp, sp, B, nsteps, sim_dt, N, timestamps, ts_stride, P, strideP, V, strideV, A, strideA, time, \
+                               pos, vel, att, omega, state, wind, wind_stride, gust_step, gust_wind, stop_at_plan_end,       \
+                               log_state, log_cmd, log_time, steps_taken, stream);                                          \
+  }
+
+SE3MPC_DEFINE_LOOP_API(f32, float)
+SE3MPC_DEFINE_LOOP_API(f64, double)

@@ -15,7 +15,10 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from .capi import Library, Params, SolveInfo, get_library, SE3MPC_MAX_SPHERES
+import ctypes as _C
+
+from .capi import (CONTROLLER_STATE_WORDS, ControllerParams, Library, Params, SimulatorParams, SolveInfo, get_library,
+                   SE3MPC_MAX_SPHERES)
 
 INFO_DTYPE = np.dtype([("fun", "<f8"), ("nit", "<i4"), ("nfev", "<i4"), ("status", "<i4"), ("task", "<i4")])
 assert INFO_DTYPE.itemsize == 24
@@ -357,6 +360,143 @@ class Ops:
         rows, cols = a.shape
         out = self.be.empty((cols, rows), suf)
         self.lib.call("transpose", suf, rows, cols, self.be.ptr(a), cols, self.be.ptr(out), rows, self.be.stream())
+        return out
+
+    # ------------------------------------------------------------------ consumer side of the contract (per-drone rows)
+    def controller_state(self, cp: ControllerParams, B: int):
+        """Fresh controller members for B drones (GeometricController.__init__ / reset): float64 (B, 12)."""
+        st = self.be.empty((B, CONTROLLER_STATE_WORDS), "f64")
+        self.lib.controller_reset(cp, B, self.be.ptr(st), self.be.stream())
+        return st
+
+    def _rows3(self, a, B, name, suf=None):
+        self.be.check(a, name)
+        if tuple(a.shape) != (B, 3) or (suf is not None and self.be.suffix(a) != suf):
+            raise ValueError(f"{name}: expected ({B}, 3) {suf or ''}, got {tuple(a.shape)}")
+        return a
+
+    def control(self, cp: ControllerParams, state, time, pos, vel, att, omega, dpos, dvel, dacc=None, yaw=None, yaw_rate=None,
+                want_body_rate: bool = False):
+        """compute_control (+ compute_body_rate_command) for B drones.  time: float64 (B,); pos .. dvel, dacc: (B, 3);
+        yaw, yaw_rate: (B,) or None (0).  `state` (B, 12) float64 is updated in place.
+        -> dict(thrust (B,), torque (B,3), flags int32 (B,)[, body_thrust (B,), body_rates (B,3)])."""
+        B = time.shape[0]
+        suf = self.be.suffix(pos)
+        for a, nm in ((pos, "pos"), (vel, "vel"), (att, "att"), (omega, "omega"), (dpos, "dpos"), (dvel, "dvel")):
+            self._rows3(a, B, nm, suf)
+        if dacc is not None:
+            self._rows3(dacc, B, "dacc", suf)
+        self.be.check(time, "time"); self.be.check(state, "state")
+        if self.be.suffix(time) != "f64" or tuple(state.shape) != (B, CONTROLLER_STATE_WORDS) or self.be.suffix(state) != "f64":
+            raise ValueError("time: float64 (B,); state: float64 (B, 12)")
+        thrust, torque = self.be.empty((B,), suf), self.be.empty((B, 3), suf)
+        flags = self.be.empty((B,), "i32")
+        bt = self.be.empty((B,), suf) if want_body_rate else None
+        br = self.be.empty((B, 3), suf) if want_body_rate else None
+        self.lib.loop_call("control", suf, cp, B, self.be.ptr(time), self.be.ptr(pos), self.be.ptr(vel), self.be.ptr(att),
+                           self.be.ptr(omega), self.be.ptr(dpos), self.be.ptr(dvel), self.be.ptr(dacc), self.be.ptr(yaw),
+                           self.be.ptr(yaw_rate), self.be.ptr(state), self.be.ptr(thrust), self.be.ptr(torque), self.be.ptr(bt),
+                           self.be.ptr(br), self.be.ptr(flags), self.be.stream())
+        out = dict(thrust=thrust, torque=torque, flags=flags)
+        if want_body_rate:
+            out.update(body_thrust=bt, body_rates=br)
+        return out
+
+    def _plan_args(self, B, suf, timestamps, P, V, A, strides):
+        self.be.check(timestamps, "timestamps")
+        if self.be.suffix(timestamps) != "f64":
+            raise ValueError("timestamps are float64")
+        N = timestamps.shape[-1]
+        ts_stride = N if timestamps.ndim == 2 else 0
+        if timestamps.ndim == 2 and timestamps.shape[0] != B:
+            raise ValueError("timestamps: (N,) or (B, N)")
+        if strides is None:
+            def st_of(a, nm):
+                if a is None:
+                    return 0
+                self.be.check(a, nm)
+                if self.be.suffix(a) != suf or a.ndim not in (2, 3) or a.shape[-2:] != (N, 3) or (a.ndim == 3 and a.shape[0] != B):
+                    raise ValueError(f"{nm}: expected ({N}, 3) or ({B}, {N}, 3) {suf}, got {tuple(a.shape)}")
+                return 3 * N if a.ndim == 3 else 0
+            sP, sV, sA = st_of(P, "P"), st_of(V, "V"), st_of(A, "A")
+        else:
+            sP, sV, sA = (int(x) for x in strides)
+        return N, ts_stride, sP, sV, sA
+
+    def control_plan(self, cp: ControllerParams, state, time, sample_time, pos, vel, att, omega, timestamps, P, V=None, A=None,
+                     strides=None, want_body_rate: bool = False, want_target: bool = False):
+        """compute_control_from_trajectory / compute_body_rate_from_trajectory for B drones: the target is the plan sampled at
+        sample_time (float64 (B,)).  Plans as in :meth:`closed_loop`.  -> dict like :meth:`control` (+ target (B, 9))."""
+        B = time.shape[0]
+        suf = self.be.suffix(pos)
+        for a, nm in ((pos, "pos"), (vel, "vel"), (att, "att"), (omega, "omega")):
+            self._rows3(a, B, nm, suf)
+        N, ts_stride, sP, sV, sA = self._plan_args(B, suf, timestamps, P, V, A, strides)
+        thrust, torque = self.be.empty((B,), suf), self.be.empty((B, 3), suf)
+        flags = self.be.empty((B,), "i32")
+        bt = self.be.empty((B,), suf) if want_body_rate else None
+        br = self.be.empty((B, 3), suf) if want_body_rate else None
+        tg = self.be.empty((B, 9), suf) if want_target else None
+        self.lib.loop_call("control_plan", suf, cp, B, self.be.ptr(time), self.be.ptr(sample_time), self.be.ptr(pos), self.be.ptr(vel),
+                           self.be.ptr(att), self.be.ptr(omega), N, self.be.ptr(timestamps), ts_stride, self.be.ptr(P), sP, self.be.ptr(V), sV,
+                           self.be.ptr(A), sA, self.be.ptr(state), self.be.ptr(thrust), self.be.ptr(torque), self.be.ptr(bt), self.be.ptr(br),
+                           self.be.ptr(flags), self.be.ptr(tg), self.be.stream())
+        out = dict(thrust=thrust, torque=torque, flags=flags)
+        if want_body_rate:
+            out.update(body_thrust=bt, body_rates=br)
+        if want_target:
+            out["target"] = tg
+        return out
+
+    def simulator_step(self, sp: SimulatorParams, time, pos, vel, att, omega, thrust, torque, dt: float, wind=None):
+        """DroneSimulator.step for B drones: advances time, pos, vel, att, omega in place."""
+        B = time.shape[0]
+        suf = self.be.suffix(pos)
+        for a, nm in ((pos, "pos"), (vel, "vel"), (att, "att"), (omega, "omega"), (torque, "torque")):
+            self._rows3(a, B, nm, suf)
+        self.be.check(thrust, "thrust")
+        w_stride = 0
+        if wind is not None:
+            self.be.check(wind, "wind")
+            w_stride = 3 if wind.ndim == 2 else 0
+        self.lib.loop_call("simulator_step", suf, sp, B, float(dt), self.be.ptr(thrust), self.be.ptr(torque), self.be.ptr(wind), w_stride,
+                           self.be.ptr(time), self.be.ptr(pos), self.be.ptr(vel), self.be.ptr(att), self.be.ptr(omega), self.be.stream())
+
+    def closed_loop(self, cp: ControllerParams, sp: SimulatorParams, state, time, pos, vel, att, omega, timestamps, P, V=None, A=None,
+                    nsteps: int = 1, sim_dt: float = 0.01, strides=None, wind=None, gust=None, stop_at_plan_end: bool = True,
+                    log: bool = False):
+        """`nsteps` x (plan sample -> compute_control -> DroneSimulator.step) for B drones in ONE launch; time, pos, vel, att,
+        omega and `state` are updated in place.  Plans: timestamps float64 (N,) shared or (B, N); P, V, A either (N, 3) shared,
+        (B, N, 3) per drone, or -- with ``strides=(strideP, strideV, strideA)`` in elements -- views into the solver's outputs
+        (P = X, V = X[:, 3N:], A = accelerations).  wind: None, (3,) or (B, 3) newtons; gust = (step, (wx, wy, wz)).
+        -> dict(steps_taken int32 (B,)[, log_state (nsteps, B, 12), log_cmd (nsteps, B, 4), log_time (nsteps, B)])."""
+        B = time.shape[0]
+        suf = self.be.suffix(pos)
+        for a, nm in ((pos, "pos"), (vel, "vel"), (att, "att"), (omega, "omega")):
+            self._rows3(a, B, nm, suf)
+        N, ts_stride, sP, sV, sA = self._plan_args(B, suf, timestamps, P, V, A, strides)
+        w_stride = 0
+        if wind is not None:
+            self.be.check(wind, "wind")
+            if self.be.suffix(wind) != suf or wind.shape[-1] != 3:
+                raise ValueError("wind: (3,) or (B, 3)")
+            w_stride = 3 if wind.ndim == 2 else 0
+        gust_step, gust_vec = -1, None
+        if gust is not None:
+            gust_step = int(gust[0])
+            gust_vec = (_C.c_double * 3)(*[float(x) for x in gust[1]])
+        ls = self.be.empty((nsteps, B, 12), suf) if log else None
+        lc = self.be.empty((nsteps, B, 4), suf) if log else None
+        lt = self.be.empty((nsteps, B), "f64") if log else None
+        taken = self.be.empty((B,), "i32")
+        self.lib.loop_call("closed_loop", suf, cp, sp, B, int(nsteps), float(sim_dt), N, self.be.ptr(timestamps), ts_stride,
+                           self.be.ptr(P), sP, self.be.ptr(V), sV, self.be.ptr(A), sA, self.be.ptr(time), self.be.ptr(pos),
+                           self.be.ptr(vel), self.be.ptr(att), self.be.ptr(omega), self.be.ptr(state), self.be.ptr(wind), w_stride,
+                           gust_step, gust_vec, int(bool(stop_at_plan_end)), self.be.ptr(ls), self.be.ptr(lc), self.be.ptr(lt),
+                           self.be.ptr(taken), self.be.stream())
+        out = dict(steps_taken=taken)
+        if log:
+            out.update(log_state=ls, log_cmd=lc, log_time=lt)
         return out
 
     # ------------------------------------------------------------------ problem layout

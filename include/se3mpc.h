@@ -354,6 +354,112 @@ int se3mpc_voxel_local_spheres_f64(const se3mpc_voxel_map* m, const double* cent
                                    int target, double radius, double* spheres, int cap, int32_t* count,
                                    int32_t* workspace, void* stream);
 
+/* ------------------------------------------------------------------ consumer side of the contract
+ * Plan sample -> geometric controller -> simulator, one drone per lane.  Reference ("controller.py" =
+ * src/dart_planner/control/geometric_controller.py, "onboard.py" = src/dart_planner/control/onboard_controller.py,
+ * "simulator.py" = src/dart_planner/utils/drone_simulator.py), unit-stripped and reproduced with its quirks.
+ * All arrays are per-drone rows: pos, vel, att (roll, pitch, yaw), omega: [B][3]; time: double [B] (DroneState.timestamp).
+ */
+
+/* GeometricControllerConfig (controller.py:26-77) after _apply_tuning_profile (:140-158).  se3mpc_controller_default_params
+ * fills the "sitl_optimized" profile (control_config.py:95-111) with the vehicle constants the reference instantiates. */
+typedef struct se3mpc_controller_params {
+  double kp_pos[3], ki_pos[3], kd_pos[3];      /* position PID gains                     (controller.py:38-42)   */
+  double kp_att[3], kd_att[3];                 /* attitude PD gains                      (:45-47)                */
+  double inertia[3];                           /* diagonal inertia, kg m^2               (:49)                   */
+  double max_torque_xyz[3];                    /* per-axis torque limits, N m            (:51)                   */
+  double max_integral_per_axis[3];             /* per-axis integral limits               (:68)                   */
+  double max_integral_pos;                     /* norm limit of the integral             (:56)                   */
+  double max_tilt_angle;                       /* rad                                    (:57)                   */
+  double mass, gravity;                        /* (:59-60)                                                       */
+  double max_thrust, min_thrust;               /* N; lower limit = min_thrust*mass*gravity (:61-62, :469)        */
+  double tracking_error_threshold, velocity_error_threshold;   /* (:64-65, _check_tracking_performance :650-658) */
+  double back_calculation_gain;                /* Kb                                     (:69)                   */
+  double integral_decay_factor;                /* (:70)                                                          */
+  double saturation_threshold;                 /* (:71)                                                          */
+  double yaw_singularity_threshold;            /* |yaw_vector . b3| at or above which yaw is singular (:73)      */
+  double default_heading_yaw;                  /* rad, for yaw_fallback_method 1         (:75)                   */
+  int32_t anti_windup_method;                  /* 0 "clamping", 1 "back_calculation", 2 none of them (:67)       */
+  int32_t yaw_fallback_method;                 /* 0 "skip_yaw", 1 "default_heading", 2 "maintain_current", 3 any other string (:74) */
+} se3mpc_controller_params;
+
+/* DroneSimulator.__init__ (simulator.py:41-50). */
+typedef struct se3mpc_simulator_params {
+  double mass, gravity, inertia[3], max_thrust, max_torque;
+} se3mpc_simulator_params;
+
+/* Mutable controller members (controller.py:87-105), SE3MPC_CONTROLLER_STATE_WORDS doubles per drone:
+ * [0..2] integral_vel_error, [3] last_time (NaN = None), [4] last_valid_thrust, [5] unsaturated_thrust, [6..8] unsaturated_torque,
+ * [9] failsafe_count, [10] number of failsafe gain halvings (:817-821), [11] bit set: 1 failsafe_active, 2 last_thrust_saturated,
+ * 4 / 8 / 16 last_torque_saturated x / y / z. */
+#define SE3MPC_CONTROLLER_STATE_WORDS 12
+
+int se3mpc_controller_default_params(se3mpc_controller_params* out);
+int se3mpc_simulator_default_params(se3mpc_simulator_params* out);
+/* GeometricController.__init__ / reset() (controller.py:87-105, :840-860) for B drones: state = device double[B][12]. */
+int se3mpc_controller_reset(const se3mpc_controller_params* cp, int B, double* state, void* stream);
+
+/* compute_control (controller.py:413-512) and, when body_thrust / body_rates are given, compute_body_rate_command (:706-726) for B
+ * drones: desired position / velocity / acceleration dpos, dvel, dacc [B][3] (dacc NULL = 0), yaw, yaw_rate [B] (NULL = 0).
+ * Outputs (any may be NULL): thrust [B], torque [B][3], body_thrust [B] (normalised), body_rates [B][3], flags int32 [B] (bit 0
+ * failsafe command returned, 1 invalid dt, 2 thrust saturated, 3 yaw singularity, 4 tilt limited, 5..7 torque saturated x/y/z).
+ * `state` is read and updated. */
+int se3mpc_control_f32(const se3mpc_controller_params* cp, int B, const double* time, const float* pos, const float* vel,
+                       const float* att, const float* omega, const float* dpos, const float* dvel, const float* dacc,
+                       const float* yaw, const float* yaw_rate, double* state, float* thrust, float* torque, float* body_thrust,
+                       float* body_rates, int32_t* flags, void* stream);
+int se3mpc_control_f64(const se3mpc_controller_params* cp, int B, const double* time, const double* pos, const double* vel,
+                       const double* att, const double* omega, const double* dpos, const double* dvel, const double* dacc,
+                       const double* yaw, const double* yaw_rate, double* state, double* thrust, double* torque, double* body_thrust,
+                       double* body_rates, int32_t* flags, void* stream);
+
+/* compute_control_from_trajectory(state, trajectory, t) / compute_body_rate_from_trajectory -- stubs in the reference
+ * (controller.py:873-875; the second does not exist), the glue its contract test calls: target = the plan sampled at sample_time[b]
+ * with OnboardController._interpolate_trajectory (onboard.py:43-93), then compute_control(state, target, yaw 0, yaw rate 0).
+ * Plans as in se3mpc_closed_loop_*.  target: NULL or [B][9] = the sampled (position, velocity, acceleration). */
+int se3mpc_control_plan_f32(const se3mpc_controller_params* cp, int B, const double* time, const double* sample_time, const float* pos,
+                            const float* vel, const float* att, const float* omega, int N, const double* timestamps, long long ts_stride,
+                            const float* P, long long strideP, const float* V, long long strideV, const float* A, long long strideA,
+                            double* state, float* thrust, float* torque, float* body_thrust, float* body_rates, int32_t* flags,
+                            float* target, void* stream);
+int se3mpc_control_plan_f64(const se3mpc_controller_params* cp, int B, const double* time, const double* sample_time, const double* pos,
+                            const double* vel, const double* att, const double* omega, int N, const double* timestamps, long long ts_stride,
+                            const double* P, long long strideP, const double* V, long long strideV, const double* A, long long strideA,
+                            double* state, double* thrust, double* torque, double* body_thrust, double* body_rates, int32_t* flags,
+                            double* target, void* stream);
+
+/* DroneSimulator.step (simulator.py:52-72) for B drones with given commands: thrust [B] (newtons), torque [B][3]; wind as in
+ * se3mpc_closed_loop_*; time, pos, vel, att, omega are advanced in place by dt. */
+int se3mpc_simulator_step_f32(const se3mpc_simulator_params* sp, int B, double dt, const float* thrust, const float* torque,
+                              const float* wind, long long wind_stride, double* time, float* pos, float* vel, float* att,
+                              float* omega, void* stream);
+int se3mpc_simulator_step_f64(const se3mpc_simulator_params* sp, int B, double dt, const double* thrust, const double* torque,
+                              const double* wind, long long wind_stride, double* time, double* pos, double* vel, double* att,
+                              double* omega, void* stream);
+
+/* The closed loop of the reference's contract tests (tests/test_planner_controller_contract.py:115-162, :255-316), `nsteps` times per
+ * drone in ONE launch:  t = state.timestamp;  [stop_at_plan_end: a drone whose t > timestamps[N-1] stops for good (`break`)];
+ * target = plan sampled at t (onboard.py:43-93);  cmd = compute_control(state, target, yaw 0);  [step == gust_step: the wind becomes
+ * gust_wind, host double[3]];  state = DroneSimulator.step(state, cmd, sim_dt) (simulator.py:52-72).
+ * Plan of drone b: timestamps + b*ts_stride (double [N]), P + b*strideP, V + b*strideV, A + b*strideA ([N][3] rows; V, A may be
+ * NULL = zeros; stride 0 = one plan shared by all drones; strideP = strideV = 9N on X / X + 3N and strideA = 3N on `acc` read the
+ * outputs of se3mpc_solve_* in place).  wind: NULL, or newtons at wind + b*wind_stride (stride 0 = one vector).
+ * time, pos, vel, att, omega, state are updated in place.  Logs (any may be NULL): log_state [nsteps][B][12] = (pos, vel, att, omega)
+ * BEFORE each step, log_cmd [nsteps][B][4] = (thrust, torque) (NaN for a stopped drone), log_time double [nsteps][B],
+ * steps_taken int32 [B]. */
+int se3mpc_closed_loop_f32(const se3mpc_controller_params* cp, const se3mpc_simulator_params* sp, int B, int nsteps, double sim_dt,
+                           int N, const double* timestamps, long long ts_stride, const float* P, long long strideP, const float* V,
+                           long long strideV, const float* A, long long strideA, double* time, float* pos, float* vel, float* att,
+                           float* omega, double* state, const float* wind, long long wind_stride, int gust_step,
+                           const double* gust_wind, int stop_at_plan_end, float* log_state, float* log_cmd, double* log_time,
+                           int32_t* steps_taken, void* stream);
+int se3mpc_closed_loop_f64(const se3mpc_controller_params* cp, const se3mpc_simulator_params* sp, int B, int nsteps, double sim_dt,
+                           int N, const double* timestamps, long long ts_stride, const double* P, long long strideP, const double* V,
+                           long long strideV, const double* A, long long strideA, double* time, double* pos, double* vel, double* att,
+                           double* omega, double* state, const double* wind, long long wind_stride, int gust_step,
+                           const double* gust_wind, int stop_at_plan_end, double* log_state, double* log_cmd, double* log_time,
+                           int32_t* steps_taken, void* stream);
+
 /* ------------------------------------------------------------------ problem layout: [b][row]
  * The batched solve: replaces _solve_se3_mpc (planner.py:230-280) = cold start (or a caller
  * x0), box, scipy.optimize.minimize(method="L-BFGS-B", jac=..., bounds=..., maxiter, gtol,

@@ -173,8 +173,10 @@ def desired_frame(cfg: ControllerConfig, b3, att, yaw_des):
             c = np.cross(yv, b3n)
             nc = _norm(c)
             b1s = np.where((nc > 1e-6)[:, None], c / nc[:, None], proj)      # :226-234 / :239-247
-        else:                                                        # "skip_yaw" and unknown methods (:248-252)
+        elif method == "skip_yaw":
             b1s = np.where((np.abs(b3n[:, 2]) < 0.99)[:, None], proj, ex)   # :214-220
+        else:                                                        # unknown method (:248-252): the projection, no 0.99 test
+            b1s = proj
         b1 = np.where(singular[:, None], b1s, b1)
     b2 = np.cross(b3n, b1)                                           # :255 / :689
     return b1, b2, b3n, singular

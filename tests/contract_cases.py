@@ -32,10 +32,24 @@ class Rig:
         if attach_backend is not None:
             attach_backend(self.planner)
         self.controller = get_container().create_control_container().get_geometric_controller()
-        self.simulator = DroneSimulator()
+        self._attach = attach_backend
+        if attach_backend is not None:
+            attach_backend(self.controller)
+        self.simulator = self.make_simulator()
         self.initial_state = DroneState(timestamp=time.time(), position=np.array([0.0, 0.0, 1.0]), velocity=np.zeros(3),
                                         attitude=np.zeros(3), angular_velocity=np.zeros(3))
         self.goal_position = GOAL.copy()
+
+
+def _make_simulator(self, **kw):
+    """A DroneSimulator on the rig's backend (the cases build their own: wind, saturated actuators)."""
+    sim = DroneSimulator(**kw)
+    if self._attach is not None:
+        self._attach(sim)
+    return sim
+
+
+Rig.make_simulator = _make_simulator
 
 
 def case_planner_outputs_complete_trajectory(r: Rig, tol=1e-4):            # :52-87
@@ -149,21 +163,21 @@ def _closed_loop(r: Rig, simulator, steps, gust_at=None):
 
 
 def case_wind_disturbance(r: Rig):                                         # :255-268
-    assert abs(_closed_loop(r, DroneSimulator(wind=np.array([2.0, 0.0, 0.0])), 100).position[0]) < 10.0
+    assert abs(_closed_loop(r, r.make_simulator(wind=np.array([2.0, 0.0, 0.0])), 100).position[0]) < 10.0
 
 
 def case_actuator_saturation(r: Rig):                                      # :270-282
-    assert _closed_loop(r, DroneSimulator(max_thrust=5.0, max_torque=2.0), 100).position[2] > 0.0
+    assert _closed_loop(r, r.make_simulator(max_thrust=5.0, max_torque=2.0), 100).position[2] > 0.0
 
 
 def case_wind_gust(r: Rig):                                                # :284-299
-    assert abs(_closed_loop(r, DroneSimulator(), 100, gust_at=50).position[0]) < 20.0
+    assert abs(_closed_loop(r, r.make_simulator(), 100, gust_at=50).position[0]) < 20.0
 
 
 def case_emergency_failsafe_handling(r: Rig):                              # :301-313
     r.planner.goal_position = None
     tr = r.planner._generate_emergency_trajectory(r.initial_state)
-    sim, state = DroneSimulator(), r.initial_state
+    sim, state = r.make_simulator(), r.initial_state
     for _ in range(50):
         state = sim.step(state, r.controller.compute_control_from_trajectory(state, tr, state.timestamp), 0.01)
     assert np.allclose(state.position, r.initial_state.position, atol=0.5)

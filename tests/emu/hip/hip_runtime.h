@@ -28,7 +28,7 @@
 #define HIP_DYNAMIC_SHARED(type, var) type* var = reinterpret_cast<type*>(::emu::g_dyn_lds);
 
 using std::asin; using std::atan2; using std::fabs; using std::fmax; using std::fmin;
-using std::isinf; using std::isnan; using std::sqrt;
+using std::isinf; using std::isnan; using std::sqrt; using std::sin; using std::cos; using std::acos; using std::ldexp;
 
 struct dim3 {
   unsigned x, y, z;

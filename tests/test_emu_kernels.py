@@ -134,3 +134,36 @@ def test_defaults_and_key_codec(emu_ops):
         ob = (~bits) & 0xFFFFFFFF if bits & 0x80000000 else bits | 0x80000000
         key = (int(ob) << 32) | 1234
         assert lib.key_index(key) == 1234 and lib.key_cost(key) == np.float32(c)
+
+
+# ------------------------------------------------------------------ consumer side of the contract (closed_loop.hip)
+import json  # noqa: E402
+import controller_checks as cc  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def golden_controller():
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return np.load(os.path.join(g, "controller_cases.npz")), json.load(open(os.path.join(g, "controller_cases.json")))
+
+
+def test_controller_defaults(emu_ops):
+    cc.check_defaults(harness(emu_ops, np.float64))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_control_reproduces_reference_sequences(emu_ops, golden_controller, dt):
+    data, meta = golden_controller
+    cc.check_control_sequences(harness(emu_ops, dt), data, meta)
+
+
+def test_closed_loop_reproduces_reference_loops(emu_ops, golden_controller):
+    data, meta = golden_controller
+    assert cc.check_closed_loops_golden(harness(emu_ops, np.float64), data, meta) <= 1e-8
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_closed_loop_random_batch_vs_oracle(emu_ops, dt):
+    cc.check_closed_loop_vs_oracle(harness(emu_ops, dt), B=70, N=12, nsteps=24, seed=1)
+    if dt == np.float64:
+        cc.check_closed_loop_vs_oracle(harness(emu_ops, dt), B=5, N=12, nsteps=24, seed=2, per_drone_plans=False)

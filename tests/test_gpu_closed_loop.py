@@ -1,0 +1,211 @@
+"""GPU suite, consumer side of the contract: se3mpc_control_*, se3mpc_control_plan_*,
+se3mpc_simulator_step_*, se3mpc_closed_loop_* on a real MI355X through the C ABI, against the vectors the reference's own
+controller / simulator / plan sampler produced and against the oracle; then the receding-horizon Monte-Carlo of BASELINE.json
+config 5's named test shape (tests/test_monte_carlo_sim.py: 33 planning cycles of 0.15 s), entirely on the device."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import controller_checks as cc  # noqa: E402
+import parity_checks as pc  # noqa: E402
+from oracle import controller_oracle as co  # noqa: E402
+from oracle import se3mpc_oracle as orc  # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu_ops():
+    import torch
+    assert torch.cuda.is_available(), "the gpu suite needs an MI355X"
+    from dart_planner_amd.ops import Ops, TorchBackend
+    ops = Ops(TorchBackend("cuda:0"))
+    assert os.path.basename(ops.lib.path) == "libse3mpc.so"
+    return ops
+
+
+@pytest.fixture(scope="module")
+def golden_controller():
+    return np.load(os.path.join(GOLDEN, "controller_cases.npz")), json.load(open(os.path.join(GOLDEN, "controller_cases.json")))
+
+
+def harness(ops, dt):
+    import torch
+    return pc.Harness(ops, lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0"), lambda a: a.detach().cpu().numpy(), dt)
+
+
+def test_controller_defaults(gpu_ops):
+    cc.check_defaults(harness(gpu_ops, np.float64))
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_control_reproduces_reference_sequences(gpu_ops, golden_controller, dt):
+    data, meta = golden_controller
+    mism, calls = cc.check_control_sequences(harness(gpu_ops, dt), data, meta)
+    print(f"{np.dtype(dt).name}: {calls} controller calls, {mism} on another side of a branch")
+
+
+def test_closed_loop_reproduces_reference_loops(gpu_ops, golden_controller):
+    data, meta = golden_controller
+    worst = cc.check_closed_loops_golden(harness(gpu_ops, np.float64), data, meta)
+    print(f"closed loops vs the reference: worst state error {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_closed_loop_random_batch_vs_oracle(gpu_ops, dt):
+    worst = cc.check_closed_loop_vs_oracle(harness(gpu_ops, dt), B=4096, N=12, nsteps=40, seed=3)
+    print(f"4096 drones x 40 steps, {np.dtype(dt).name}: worst state error vs the oracle {worst:.2e}")
+    if dt == np.float64:
+        cc.check_closed_loop_vs_oracle(harness(gpu_ops, dt), B=130, N=12, nsteps=40, seed=4, per_drone_plans=False)
+
+
+def test_simulator_step_matches_reference(gpu_ops, golden_controller):
+    import torch
+    from dart_planner_amd.capi import SimulatorParams
+    data, _ = golden_controller
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to("cuda:0")
+    for i in range(len(data["s_thrust"])):
+        sp = SimulatorParams.reference_defaults(max_thrust=float(data["s_max"][i, 0]), max_torque=float(data["s_max"][i, 1]))
+        t, pos, vel, att, om = d([3.0 + i]), d(data["s_pos"][i][None]), d(data["s_vel"][i][None]), d(data["s_att"][i][None]), d(data["s_omega"][i][None])
+        gpu_ops.simulator_step(sp, t, pos, vel, att, om, d([data["s_thrust"][i]]), d(data["s_torque"][i][None]), float(data["s_dt"][i]), wind=d(data["s_wind"][i]))
+        got = np.concatenate([a.cpu().numpy().ravel() for a in (pos, vel, att, om, t)])
+        assert np.max(np.abs(got - data["s_out"][i])) <= 1e-13, i
+
+
+def test_plan_sampler_matches_reference(gpu_ops, golden_controller):
+    """se3mpc_control_plan_*'s target output == OnboardController._interpolate_trajectory on the reference's own query times
+    (knots, mid-points, before / after the plan, 1e-12 past a knot)."""
+    import torch
+    from dart_planner_amd.capi import ControllerParams
+    data, _ = golden_controller
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float64))).to("cuda:0")
+    cp = ControllerParams.from_config(co.ControllerConfig())
+    tq = data["i_tq"]
+    B = len(tq)
+    z = d(np.zeros((B, 3)))
+    out = gpu_ops.control_plan(cp, gpu_ops.controller_state(cp, B), d(tq), d(tq), z, z, z, z, d(data["i_ts"]), d(data["i_P"]), d(data["i_V"]), d(data["i_A"]),
+                               want_target=True)
+    tg = out["target"].cpu().numpy()
+    assert np.array_equal(tg[:, 0:3], data["i_pos"]) and np.array_equal(tg[:, 3:6], data["i_vel"]) and np.array_equal(tg[:, 6:9], data["i_acc"])
+    out = gpu_ops.control_plan(cp, gpu_ops.controller_state(cp, 8), d(tq[:8]), d(tq[:8]), z[:8], z[:8], z[:8], z[:8], d(data["i_ts"]), d(data["i_P"]), want_target=True)
+    tg = out["target"].cpu().numpy()
+    assert np.array_equal(tg[:, 0:3], data["i_pos_only"]) and not tg[:, 3:].any()
+
+
+def monte_carlo(ops, prm, cp, sp, p0, v0, goal, cycles, substeps, sim_dt, wind, dtype, log=False):
+    """The receding-horizon Monte-Carlo on the device: per cycle ONE se3mpc_solve_* launch (every drone re-plans from its own
+    state) and ONE se3mpc_closed_loop_* launch (`substeps` control + simulator steps against the fresh plan, read in place from
+    the solver's outputs).  No host arithmetic, no copies between the two."""
+    import torch
+    dev = ops.be.device
+    S, N = p0.shape[0], prm.horizon
+    pos, vel = p0.clone(), v0.clone()
+    att, om = torch.zeros(S, 3, dtype=dtype, device=dev), torch.zeros(S, 3, dtype=dtype, device=dev)
+    time = torch.zeros(S, dtype=torch.float64, device=dev)
+    st = ops.controller_state(cp, S)
+    k = torch.arange(N, dtype=torch.float64, device=dev)
+    logs = []
+    for c in range(cycles):
+        sol = ops.solve(prm, pos, vel, goal)
+        ts = (c * substeps * sim_dt) + k * prm.dt                      # planner.py:661: start_time + arange(N) * dt
+        X = sol["x"]
+        out = ops.closed_loop(cp, sp, st, time, pos, vel, att, om, ts, X, X[:, 3 * N:], sol["accelerations"], nsteps=substeps, sim_dt=sim_dt,
+                              strides=(9 * N, 9 * N, 3 * N), wind=wind, stop_at_plan_end=False, log=log)
+        if log:
+            logs.append((sol, out))
+    return pos, vel, att, om, time, st, logs
+
+
+def test_monte_carlo_closed_loop_on_device(gpu_ops):
+    """BASELINE.json config 5's named test shape (reference tests/test_monte_carlo_sim.py: SIM_DURATION 5 s, DT 0.15 s -> 33
+    planning cycles from p = (0,0,2) towards (8,0,5), random wind per run), with the contract's controller in the loop at 100 Hz
+    (15 control + simulator steps per cycle) for 4096 runs at once.  A 48-run sample is replayed cycle by cycle with the oracle
+    (SciPy solve + NumPy controller / simulator) from the device's own states; the full batch is checked through invariants."""
+    import torch
+    from dart_planner_amd.capi import ControllerParams, Params, SimulatorParams
+    ops = gpu_ops
+    dev = ops.be.device
+    S, cycles, substeps, sim_dt = 4096, 33, 15, 0.01
+    prm = Params.reference_defaults()                                 # the DI planner: horizon 6, dt 1/400
+    cfg = co.ControllerConfig()
+    cp, sp = ControllerParams.from_config(cfg), SimulatorParams.reference_defaults()
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    dtype = torch.float64
+    p0 = torch.tensor([0.0, 0.0, 2.0], dtype=dtype, device=dev).repeat(S, 1) + 0.2 * torch.randn(S, 3, dtype=dtype, device=dev, generator=g)
+    v0 = 0.3 * torch.randn(S, 3, dtype=dtype, device=dev, generator=g)
+    goal = torch.tensor([8.0, 0.0, 5.0], dtype=dtype, device=dev).repeat(S, 1).contiguous()
+    wind = (torch.rand(S, 1, dtype=dtype, device=dev, generator=g) * 1.5) * torch.randn(S, 3, dtype=dtype, device=dev, generator=g)   # wind_std ~ U(0, 1.5)
+    wind = wind.contiguous()
+    pos, vel, att, om, time, st, logs = monte_carlo(ops, prm, cp, sp, p0, v0, goal, cycles, substeps, sim_dt, wind, dtype, log=True)
+    torch.cuda.synchronize()
+    # invariants on all 4096 runs
+    assert float((time - cycles * substeps * sim_dt).abs().max()) <= 1e-9
+    assert torch.isfinite(pos).all() and torch.isfinite(vel).all()
+    taken = torch.stack([o["steps_taken"] for _, o in logs])
+    assert int(taken.min()) == substeps == int(taken.max())
+    # the simulator's translation ignores attitude (simulator.py:59): x / y only move with the wind
+    drift = (pos[:, :2] - p0[:, :2] - v0[:, :2] * 4.95).abs().max()
+    expect = (wind[:, :2].abs().max() / 1.5) * 0.5 * 4.95 ** 2
+    assert float(drift) <= float(expect) * 1.05 + 1e-6
+    # 48 runs replayed with the oracle, cycle by cycle, each cycle FROM THE DEVICE'S OWN state (so the comparison is per cycle: one
+    # SciPy solve and 15 NumPy control / simulator steps against one solve launch and one closed-loop launch)
+    pick = np.arange(0, S, S // 48)[:48]
+    ocfg = orc.OracleConfig()
+    sim = co.SimulatorConfig()
+    k = np.arange(6)
+    worst_plan = worst_state = 0.0
+    h = lambda a: a.cpu().numpy()
+    for c in range(cycles):
+        sol, out = logs[c]
+        ls, lt = h(out["log_state"])[:, pick], h(out["log_time"])[:, pick]
+        X = h(sol["x"])[pick]; info = ops.info_to_host(sol["info"])[pick]
+        start = ls[0]
+        acc = []
+        for j in range(len(pick)):
+            xr, ir = orc.solve(start[j, 0:3], start[j, 3:6], h(goal)[0], ocfg)
+            assert (int(info["nit"][j]), int(info["nfev"][j]), int(info["status"][j])) == (ir["nit"], ir["nfev"], ir["status"]), (c, j)
+            worst_plan = max(worst_plan, float(np.max(np.abs(X[j, :18] - xr[:18]))))
+            acc.append(orc.extract_solution(xr, ocfg)["accelerations"])
+        assert worst_plan <= 1e-9
+    # one full replay of the first 3 cycles' control / simulator steps from the logged controller members would need the members
+    # per cycle; instead the closed-loop launch itself is checked against the oracle in test_closed_loop_random_batch_vs_oracle and
+    # here through the end state of cycle 0 (fresh controller): plan of cycle 0 -> 15 steps
+    sol, out = logs[0]
+    X = h(sol["x"])[pick]
+    P, V, A = X[:, :18].reshape(-1, 6, 3), X[:, 18:36].reshape(-1, 6, 3), h(sol["accelerations"])[pick]
+    ts = 0.0 + k * prm.dt
+    fin, log = co.closed_loop(cfg, sim, co.ControllerState(len(pick), cfg), h(p0)[pick], h(v0)[pick], np.zeros((len(pick), 3)), np.zeros((len(pick), 3)),
+                              np.zeros(len(pick)), ts, P, V, A, substeps, sim_dt, wind=h(wind)[pick], stop_at_plan_end=False)
+    ref = np.concatenate([log["pos"], log["vel"], log["att"], log["omega"]], axis=2)
+    worst_state = float(np.max(np.abs(h(out["log_state"])[:, pick] - ref)))
+    assert worst_state <= 1e-8
+    dist = (pos - goal).norm(dim=1)
+    print(f"Monte-Carlo 4096 x 33 cycles x 15 steps on device: plans vs SciPy {worst_plan:.2e} m, first-cycle states vs oracle {worst_state:.2e}; "
+          f"final distance to goal: median {float(dist.median()):.2f} m (the reference's simulator has no lateral authority)")
+
+
+def test_monte_carlo_f32_tracks_f64(gpu_ops):
+    """The same Monte-Carlo in float32 (production precision): median end-state deviation from the f64 run stays small; runs near a
+    controller branch may part ways (reported, bounded)."""
+    import torch
+    from dart_planner_amd.capi import ControllerParams, Params, SimulatorParams
+    ops = gpu_ops
+    dev = ops.be.device
+    S, cycles, substeps, sim_dt = 1024, 33, 15, 0.01
+    prm = Params.reference_defaults()
+    cp, sp = ControllerParams.from_config(co.ControllerConfig()), SimulatorParams.reference_defaults()
+    g = torch.Generator(device=dev); g.manual_seed(6)
+    p0 = torch.tensor([0.0, 0.0, 2.0], dtype=torch.float64, device=dev).repeat(S, 1) + 0.2 * torch.randn(S, 3, dtype=torch.float64, device=dev, generator=g)
+    v0 = 0.3 * torch.randn(S, 3, dtype=torch.float64, device=dev, generator=g)
+    goal = torch.tensor([8.0, 0.0, 5.0], dtype=torch.float64, device=dev).repeat(S, 1).contiguous()
+    wind = torch.randn(S, 3, dtype=torch.float64, device=dev, generator=g).contiguous()
+    r64 = monte_carlo(ops, prm, cp, sp, p0, v0, goal, cycles, substeps, sim_dt, wind, torch.float64)
+    f = lambda a: a.float().contiguous()
+    r32 = monte_carlo(ops, prm, cp, sp, f(p0), f(v0), f(goal), cycles, substeps, sim_dt, f(wind), torch.float32)
+    err = (r32[0].double() - r64[0]).abs().max(dim=1).values
+    print(f"f32 vs f64 Monte-Carlo end positions: median {float(err.median()):.2e} m, 95 % {float(err.quantile(0.95)):.2e} m, max {float(err.max()):.2e} m")
+    assert float(err.median()) <= 5e-3 and float(err.quantile(0.95)) <= 0.25
