@@ -625,15 +625,85 @@ def config_legs(torch, ops, dev, min_ms):
 
 
 def iterated_leg(torch, ops, dev, B, N, min_ms):
-    if not hasattr(ops, "rollout_iterate"):
-        return None
-    return None
+    """The on-device iteration loop (se3mpc_rollout_iterate_*): K projected-gradient iterations of the shooting form + one last
+    evaluation in ONE launch, thrust sequences resident in registers, against the same K + 1 evaluations issued as one launch each
+    (`single_launch` leg).  Same batch (8192 x horizon 30), ring of distinct batches, hipGraph replay, HIP-event time."""
+    from dart_planner_amd.capi import Params
+    prm = Params.reference_defaults(horizon=N)
+    slot = 4 * B * ((9 + 3 * N) + (1 + 6 * N))
+    ring = max(2, math.ceil(320 * 2 ** 20 / slot))
+    p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=77)
+    Tout = torch.empty_like(T)
+    step = 0.9
+    out = {"what": f"horizon={N}, batch={B}: K iterations of T <- clip(T - {step} dcost/dT) + a final evaluation per launch; "
+                   "K + 1 rollouts per trajectory per launch, HBM traffic of one", "per_K": []}
+    base_us = None
+    for K in (0, 1, 4, 16, 64):
+        nl = min(ring, 256)
+        body = lambda: [ops.rollout_iterate(prm, p0[i], v0[i], goal[i], T[i], K, step, out=(Tout[i], cost[i], grad[i])) for i in range(nl)]
+        body(); torch.cuda.synchronize()
+        graph = capture(torch, dev, body)
+        ms1 = device_ms(torch, graph.replay, 2)
+        reps = max(2, math.ceil(min_ms / max(ms1, 1e-6)))
+        us = device_ms(torch, graph.replay, reps) / nl * 1e3
+        del graph
+        if K == 0:
+            base_us = us
+        hbm = 4 * (9 + 3 * N) + 4 * (1 + 6 * N)                 # per trajectory: read p0, v0, goal, T; write T, gradient, cost
+        out["per_K"].append({"K": K, "launch_us": us, "us_per_iteration": None if K == 0 else (us - base_us) / K,
+                             "rollouts_per_s": B * (K + 1) / (us * 1e-6), "hbm_bytes_per_launch": hbm * B,
+                             "hbm_GB_per_s": hbm * B / (us * 1e-6) / 1e9,
+                             "rollout_equivalent_GB_per_s": 4 * (6 * N + 10) * B * (K + 1) / (us * 1e-6) / 1e9})
+    out["note"] = ("rollout_equivalent_GB_per_s prices every in-register rollout at the 4*(6N+10) B a stand-alone launch would move; it may "
+                   "exceed the HBM peak -- the iterations in between touch no memory -- and is NOT a roofline fraction; the bound of this "
+                   "kernel is the dependent-instruction latency of the 2N-step sweep per iteration")
+    return out
 
 
 def closed_loop_leg(torch, ops, dev):
-    if not hasattr(ops, "closed_loop"):
-        return None
-    return None
+    """BASELINE.json config 5's named test shape (reference tests/test_monte_carlo_sim.py: 33 planning cycles of 0.15 s) as a
+    receding-horizon Monte-Carlo entirely on the device: per cycle ONE batched solve launch (every run re-plans from its own state)
+    and ONE closed-loop launch (15 x plan sample -> geometric controller -> simulator at 100 Hz, plans read in place from the solver's
+    outputs).  4096 runs, float32; wall time with one synchronise at the end."""
+    from dart_planner_amd.capi import ControllerParams, Params, SimulatorParams
+    S, cycles, substeps, sim_dt = 4096, 33, 15, 0.01
+    prm = Params.reference_defaults()
+    N = prm.horizon
+    cp, sp = ops.lib.controller_default_params(), ops.lib.simulator_default_params()
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    res = {}
+    for name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        p0 = torch.tensor([0.0, 0.0, 2.0], dtype=dtype, device=dev).repeat(S, 1) + 0.2 * torch.randn(S, 3, dtype=dtype, device=dev, generator=g)
+        v0 = 0.3 * torch.randn(S, 3, dtype=dtype, device=dev, generator=g)
+        goal = torch.tensor([8.0, 0.0, 5.0], dtype=dtype, device=dev).repeat(S, 1).contiguous()
+        wind = torch.randn(S, 3, dtype=dtype, device=dev, generator=g).contiguous()
+        k = torch.arange(N, dtype=torch.float64, device=dev)
+        stamps = [(c * substeps * sim_dt) + k * prm.dt for c in range(cycles)]
+
+        def run():
+            pos, vel = p0.clone(), v0.clone()
+            att, om = torch.zeros_like(p0), torch.zeros_like(p0)
+            time_ = torch.zeros(S, dtype=torch.float64, device=dev)
+            st = ops.controller_state(cp, S)
+            for c in range(cycles):
+                sol = ops.solve(prm, pos, vel, goal)
+                X = sol["x"]
+                ops.closed_loop(cp, sp, st, time_, pos, vel, att, om, stamps[c], X, X[:, 3 * N:], sol["accelerations"], nsteps=substeps,
+                                sim_dt=sim_dt, strides=(9 * N, 9 * N, 3 * N), wind=wind, stop_at_plan_end=False)
+            return pos
+        run(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pos = run()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        el = float(np.median(ts))
+        res[name] = {"wall_ms_per_monte_carlo": el * 1e3, "runs_per_s": S / el, "plans_per_s": S * cycles / el,
+                     "control_steps_per_s": S * cycles * substeps / el, "finite": bool(torch.isfinite(pos).all())}
+    return {"what": f"{S} closed-loop runs x {cycles} planning cycles x {substeps} control+simulator steps (horizon-6 plans, DI defaults), "
+                    "2 launches per cycle, no host arithmetic", **res}
 
 
 def sweep(torch, ops, prm, dev, N):

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
@@ -621,6 +622,210 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
       else total += rollout_axis_rev<R, GRAD, STATES, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, T, gradT, Pout, Vout);
     }
     rollout_epilogue<R>(live, b, total, cost, key != nullptr ? key + blk : nullptr, index_base);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K iterations of the shooting form in ONE launch: projected gradient descent on the thrust
+// sequence of every trajectory,
+//     T <- clip(T - step * dcost/dT, thrust box of planner.py:390-400),
+// `iters` times, then one last evaluation of (cost, gradient) at the final T.  A launch of the plain rollout kernel costs
+// ~4.4 us for an 8192-trajectory batch whatever it does (6 MB = 1 us of HBM time; the rest is launch + the load -> 60
+// dependent steps -> store chain), so a sampling / descent loop driven from the host pays that per iteration.  Here the
+// thrust sequence of a lane stays in REGISTERS between iterations: iteration 0 reads T (3N rows), the last one writes T and
+// the gradient; the iterations in between touch no memory at all.  The three axes are independent double integrators, the
+// cost is separable in them and the box is per axis, so the three axis wavefronts of a workgroup iterate without ever
+// talking to each other; their partial costs meet in LDS once, for the final cost and the fused argmin key.
+// The gradient of step k is consumed in place: once the reverse sweep has produced g_k it no longer needs T_k (the adjoint
+// recurrences run on the stored states), so T_k is overwritten right there -- no gradient array, no second pass.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// the same expression in the in-launch loop and in the stand-alone step kernel: one fused multiply-add, then the box
+template <typename R>
+__device__ __forceinline__ R projected_update(R t, R g, R step, R lo, R hi) {
+  return fmin(fmax(fma_r(-step, g, t), lo), hi);
+}
+
+template <typename R, int N, bool EXACT, int LDAUX, int STAUX>
+__device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
+                                              const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
+                                              R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, R& cost_first) {
+  // `live`: tail lanes shadow the last trajectory (identical loads) but must not store -- Tout may alias Tin
+  const int Nn = EXACT ? N : q.N;
+  R t[N], es[N], vs[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if (EXACT || k < Nn) t[k] = lane_ld<LDAUX>(lane_buf(Tin), voff, (unsigned)(3 * k + a) * rowb);
+  }
+  const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
+  const R pinit = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
+  const R vinit = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
+  const R lo = (a == 2) ? q.tz_lo : -q.txy, hi = (a == 2) ? q.tz_hi : q.txy;      // planner.py:390-400
+  R cost = (R)0;
+#pragma unroll 1
+  for (int it = 0; it <= iters; ++it) {
+    const bool last = it == iters;
+    R p = pinit, v = vinit;
+    RolloutSums<R> s = {0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (EXACT || k < Nn) {
+        const R acc = t[k] * q.inv_mass - c.grav;
+        const R dev = t[k] - c.hov;
+        const R e = p - c.gl;
+        es[k] = e; vs[k] = v;
+        if (k == Nn - 1) s.sterm = e * e; else s.sp += e * e;
+        s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+        p = p + v * q.dt + q.half_dt2 * acc;
+        v = v + acc * q.dt;
+      }
+    }
+    s.sp += s.sterm;
+    cost = axis_cost(q, s);
+    if (it == 0) cost_first = cost;
+    R lamP = (R)0, lamV = (R)0;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+      if (EXACT || k < Nn) {
+        const R acc = t[k] * q.inv_mass - c.grav;
+        const R dev = t[k] - c.hov;
+        R g;
+        if (k == Nn - 1) {
+          g = c.c_aa * acc + c.c_tt * dev;
+          lamP = c.two_wp * ((R)1 + q.term) * es[k];
+          lamV = c.two_wv * vs[k];
+        } else {
+          g = c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV;
+          lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
+          lamP = c.two_wp * es[k] + lamP;
+        }
+        if (last) {
+          if (gradT != nullptr && live) lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, g);
+        } else {
+          t[k] = projected_update(t[k], g, step, lo, hi);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < N; ++k) {
+    if ((EXACT || k < Nn) && live) lane_st<STAUX>(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, t[k]);
+  }
+  return cost;
+}
+
+// Any horizon: the working copy of T lives in Tout (the lane's own elements, L1/L2-resident between iterations); states are
+// recovered by walking the recurrence backwards as in rollout_axis_rev.
+template <typename R>
+__device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
+                                              const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
+                                              R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, R& cost_first) {
+  // the working copy lives in Tout, so a tail lane has nothing of its own to iterate on: it leaves (no cross-lane op below)
+  if (!live) { cost_first = (R)0; return (R)0; }
+  const int N = q.N;
+  const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
+  const R pinit = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
+  const R vinit = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
+  const R lo = (a == 2) ? q.tz_lo : -q.txy, hi = (a == 2) ? q.tz_hi : q.txy;
+  if (Tin != Tout) {
+    for (int k = 0; k < N; ++k) lane_st(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, lane_ld(lane_buf(Tin), voff, (unsigned)(3 * k + a) * rowb));
+  }
+  R cost = (R)0;
+#pragma unroll 1
+  for (int it = 0; it <= iters; ++it) {
+    const bool last = it == iters;
+    R p = pinit, v = vinit, pl = pinit, vl = vinit, tk = (R)0;
+    RolloutSums<R> s = {0, 0, 0, 0, 0};
+#pragma unroll 6
+    for (int k = 0; k < N; ++k) {
+      tk = lane_ld(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb);
+      const R acc = tk * q.inv_mass - c.grav;
+      const R dev = tk - c.hov;
+      const R e = p - c.gl;
+      if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
+      s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      pl = p; vl = v;
+      p = p + v * q.dt + q.half_dt2 * acc;
+      v = v + acc * q.dt;
+    }
+    s.sp += s.sterm;
+    cost = axis_cost(q, s);
+    if (it == 0) cost_first = cost;
+    R lamP = c.two_wp * ((R)1 + q.term) * (pl - c.gl);
+    R lamV = c.two_wv * vl;
+    {
+      const R g = c.c_aa * (tk * q.inv_mass - c.grav) + c.c_tt * (tk - c.hov);
+      if (last) { if (gradT != nullptr) lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, g); }
+      else lane_st(lane_buf(Tout), voff, (unsigned)(3 * (N - 1) + a) * rowb, projected_update(tk, g, step, lo, hi));
+    }
+    R pk = pl, vk = vl;
+#pragma unroll 6
+    for (int k = N - 2; k >= 0; --k) {
+      const R tt = lane_ld(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb);
+      const R acc = tt * q.inv_mass - c.grav;
+      const R dev = tt - c.hov;
+      vk = vk - acc * q.dt;
+      pk = pk - vk * q.dt - q.half_dt2 * acc;
+      const R g = c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV;
+      if (last) { if (gradT != nullptr) lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, g); }
+      else lane_st(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, projected_update(tt, g, step, lo, hi));
+      lamV = c.two_wv * vk + q.dt * lamP + lamV;
+      lamP = c.two_wp * (pk - c.gl) + lamP;
+    }
+  }
+  return cost;
+}
+
+// FLAGS as rollout_kernel (bit 0 nt loads, bit 1 nt stores, bit 2 XCD-contiguous block order, bit 3 N is a register bucket).
+// blockIdx.y = batch of a multi-batch launch.
+template <typename R, int N, bool REG, int FLAGS>
+__global__ void __launch_bounds__(192)
+rollout_iterate_kernel(DevParams<R> q, int B, int ld, int iters, R step, const R* __restrict__ p0, const R* __restrict__ v0,
+                       const R* __restrict__ goal, const R* __restrict__ Tin, R* __restrict__ Tout, R* __restrict__ cost_first,
+                       R* __restrict__ cost, R* __restrict__ gradT, unsigned long long* __restrict__ key, uint32_t index_base) {
+  {
+    const size_t bi = blockIdx.y, ss = (size_t)3 * ld, st = (size_t)3 * q.N * ld;
+    p0 += bi * ss; v0 += bi * ss; Tin += bi * st; Tout += bi * st; cost += bi * (size_t)ld;
+    if (goal != nullptr) goal += bi * ss;
+    if (gradT != nullptr) gradT += bi * st;
+    if (cost_first != nullptr) cost_first += bi * (size_t)ld;
+    if (key != nullptr) key += bi * (size_t)gridDim.x;
+  }
+  int blk = blockIdx.x;
+  if ((FLAGS & 4) && (gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int b0 = blk * kWave + lane;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;
+  const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  __shared__ R part[2][3][kWave];
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
+  R c0 = (R)0, c;
+  if constexpr (REG) c = iterate_axis_reg<R, N, !(FLAGS & 8), (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, c0);
+  else c = iterate_axis_mem<R>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, c0);
+  part[0][a][lane] = c; part[1][a][lane] = c0;
+  __syncthreads();
+  const R total = part[0][0][lane] + part[0][1][lane] + part[0][2][lane];
+  if (a == 0 && live && cost_first != nullptr) cost_first[b] = part[1][0][lane] + part[1][1][lane] + part[1][2][lane];
+  rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
+}
+
+// One projected gradient step as its own launch: T_out = clip(T - step * g, thrust box).  The host-chained counterpart of one
+// iteration of rollout_iterate_kernel (rollout_cost_grad launch + this launch).
+template <typename R>
+__global__ void __launch_bounds__(64)
+projected_step_kernel(DevParams<R> q, int B, int ld, R step, const R* __restrict__ T, const R* __restrict__ g, R* __restrict__ Tout) {
+  const LaneIdx li = lane_index<R>(B);
+  if (!li.live) return;
+  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int rows = 3 * q.N;
+#pragma unroll 6
+  for (int r = 0; r < rows; ++r) {
+    const int a = r % 3;
+    const R lo = (a == 2) ? q.tz_lo : -q.txy, hi = (a == 2) ? q.tz_hi : q.txy;
+    const R t = lane_ld<2>(lane_buf(T), voff, (unsigned)r * rowb), gr = lane_ld<2>(lane_buf(g), voff, (unsigned)r * rowb);
+    lane_st<2>(lane_buf(Tout), voff, (unsigned)r * rowb, projected_update(t, gr, step, lo, hi));
   }
 }
 
@@ -1288,6 +1493,55 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
 }
 
 template <typename R>
+int rollout_iterate_impl(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const R* p0, const R* v0, const R* goal,
+                         const R* Tin, R* Tout, R* cost_first, R* cost, R* gradT, uint64_t* key64, uint32_t index_base, void* stream) {
+  if (nbatch < 1 || nbatch > 65535 || iters < 0 || iters > 1000000) return SE3MPC_ERR_SHAPE;
+  int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));
+  if (rc) return rc;
+  if (!std::isfinite(step)) return SE3MPC_ERR_PARAM;
+  if (B == 0) return SE3MPC_OK;
+  if (!p0 || !v0 || !Tin || !Tout || !cost || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
+  const DevParams<R> q = make_dev_params<R>(*p);
+  const int N = p->horizon, nblk = grid_for(B, kWave);
+  hipStream_t s = (hipStream_t)stream;
+  const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
+  const bool has_bucket = sizeof(R) == 4 && N > 16 && N <= 32;
+#define SE3MPC_ITER(NN, REG, FL)                                                                                              \
+  hipLaunchKernelGGL((rollout_iterate_kernel<R, NN, REG, FL>), dim3(nblk, nbatch), dim3(192), 0, s, q, B, ld, iters, (R)step, p0, v0, goal, \
+                     Tin, Tout, cost_first, cost, gradT, key, index_base)
+  if (has_reg) {
+    switch (N) {
+      case 6: SE3MPC_ITER(6, true, 7); break;
+      case 20: SE3MPC_ITER(20, true, 7); break;
+      default:
+        if constexpr (sizeof(R) == 4) {
+          if (N == 30) SE3MPC_ITER(30, true, 7);
+          else SE3MPC_ITER(50, true, 7);
+        }
+    }
+  } else if (has_bucket) {
+    if constexpr (sizeof(R) == 4) SE3MPC_ITER(32, true, 15);
+  } else {
+    SE3MPC_ITER(0, false, 7);
+  }
+#undef SE3MPC_ITER
+  return launch_status("se3mpc_rollout_iterate");
+}
+
+template <typename R>
+int projected_step_impl(const se3mpc_params* p, int B, int ld, double step, const R* T, const R* g, R* Tout, void* stream) {
+  int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));
+  if (rc) return rc;
+  if (!std::isfinite(step)) return SE3MPC_ERR_PARAM;
+  if (B == 0) return SE3MPC_OK;
+  if (!T || !g || !Tout) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(projected_step_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream, make_dev_params<R>(*p), B,
+                     ld, (R)step, T, g, Tout);
+  return launch_status("se3mpc_projected_step");
+}
+
+template <typename R>
 int is_plan_valid_impl(const se3mpc_params* p, int B, int ld, const R* P, const R* V, int32_t* valid, void* stream) {
   int rc = check_lane_args(p, B, ld, 0, sizeof(R));
   if (rc) return rc;
@@ -1436,6 +1690,16 @@ using namespace se3mpc;
                                                         uint32_t index_base, void* stream) {                             \
     return rollout_obstacles_impl<R>(p, B, ld, p0, v0, goal, T, cost, gradT, spheres, K, cmin, viol, wave_keys,          \
                                      index_base, nbatch, stream);                                                        \
+  }                                                                                                                      \
+  extern "C" int se3mpc_rollout_iterate_##SUF(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step,          \
+                                              const R* p0, const R* v0, const R* goal, const R* T_in, R* T_out, R* cost_first,   \
+                                              R* cost, R* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream) {       \
+    return rollout_iterate_impl<R>(p, B, ld, nbatch, iters, step, p0, v0, goal, T_in, T_out, cost_first, cost, gradT, wave_keys,  \
+                                   index_base, stream);                                                                          \
+  }                                                                                                                      \
+  extern "C" int se3mpc_projected_step_##SUF(const se3mpc_params* p, int B, int ld, double step, const R* T, const R* gradT,      \
+                                             R* T_out, void* stream) {                                                   \
+    return projected_step_impl<R>(p, B, ld, step, T, gradT, T_out, stream);                                              \
   }                                                                                                                      \
   extern "C" int se3mpc_is_plan_valid_##SUF(const se3mpc_params* p, int B, int ld, const R* P, const R* V,                \
                                             int32_t* valid, void* stream) {                                              \

@@ -290,6 +290,46 @@ class Ops:
                       int(index_base), self.be.stream(), params=params)
         return cost, gradT, cmin, viol
 
+    def rollout_iterate(self, params: Params, p0, v0, goal, T, iters: int, step: float, T_out=None, want_grad: bool = True,
+                        want_first_cost: bool = False, B: Optional[int] = None, out=None, wave_keys=None, index_base: int = 0):
+        """`iters` projected-gradient iterations of the shooting form in ONE launch (thrust sequences stay in registers), then one
+        last evaluation.  Single batch: p0, v0, goal (3, ld), T (3N, ld); multi-batch (grid.y): leading batch axis on every operand.
+        -> dict(T (like T), cost, gradT | None, cost_first | None).  ``out=(T_out, cost, gradT)`` reuses preallocated outputs;
+        T_out may be T itself (in place)."""
+        N = params.horizon
+        batched = T.ndim == 3
+        nb = T.shape[0] if batched else 1
+        ld = T.shape[-1]
+        lead = (nb,) if batched else ()
+        for a, rows, nm in ((p0, 3, "p0"), (v0, 3, "v0"), (T, 3 * N, "T")) + (((goal, 3, "goal"),) if params.has_goal else ()):
+            self.be.check(a, nm)
+            if tuple(a.shape) != lead + (rows, ld):
+                raise ValueError(f"{nm}: expected {lead + (rows, ld)}, got {tuple(a.shape)}")
+        suf = self.be.suffix(T)
+        if out is not None:
+            T_out, cost, gradT = out
+        else:
+            T_out = T_out if T_out is not None else self.be.empty(lead + (3 * N, ld), suf)
+            cost = self.be.empty(lead + (ld,), suf)
+            gradT = self.be.empty(lead + (3 * N, ld), suf) if want_grad else None
+        cost_first = self.be.empty(lead + (ld,), suf) if want_first_cost else None
+        nB = self._B(ld, B)
+        self.lib.call("rollout_iterate", suf, nB, ld, nb, int(iters), float(step), self.be.ptr(p0), self.be.ptr(v0),
+                      self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(T_out), self.be.ptr(cost_first),
+                      self.be.ptr(cost), self.be.ptr(gradT), self.be.ptr(wave_keys), int(index_base), self.be.stream(), params=params)
+        return dict(T=T_out, cost=cost, gradT=gradT, cost_first=cost_first)
+
+    def projected_step(self, params: Params, T, gradT, step: float, out=None, B: Optional[int] = None):
+        """One descent step as its own launch: clip(T - step * gradT, thrust box) -> (3N, ld)."""
+        N = params.horizon
+        self._lane(T, 3 * N, "T"); self._lane(gradT, 3 * N, "gradT")
+        suf = self._same(T, gradT)
+        ld = T.shape[1]
+        T_out = out if out is not None else self.be.empty((3 * N, ld), suf)
+        self.lib.call("projected_step", suf, self._B(ld, B), ld, float(step), self.be.ptr(T), self.be.ptr(gradT), self.be.ptr(T_out),
+                      self.be.stream(), params=params)
+        return T_out
+
     def is_plan_valid(self, params: Params, P, V=None, B: Optional[int] = None):
         """a16: -> int32 (ld,)."""
         N = params.horizon

@@ -212,6 +212,27 @@ int se3mpc_rollout_obstacles_batched_f64(const se3mpc_params* p, int B, int ld, 
                                          const double* spheres, int K, double* cmin, double* viol, uint64_t* wave_keys,
                                          uint32_t index_base, void* stream);
 
+/* `iters` iterations of the shooting form in ONE launch -- the on-device replacement of a host-driven optimisation loop over the
+ * rollout (north_star: "replacing DART-Planner's ... optimisation loop"; reference loop site planner.py:256-268): projected gradient
+ * descent on every trajectory's thrust sequence,  T <- clip(T - step * dcost/dT, thrust box of planner.py:390-400),  `iters` times,
+ * then one last evaluation at the final T.  The thrust sequence stays in registers between iterations: only iteration 0 reads T_in
+ * and only the last evaluation writes (T_out, cost, gradT) -- HBM traffic per launch is that of ONE rollout whatever `iters` is.
+ * iters = 0 is se3mpc_rollout_cost_grad_* plus a copy of T.  T_out may alias T_in.  cost_first: NULL or [B] = the cost at T_in;
+ * cost: [B] = the cost at T_out; gradT: NULL or [3N][ld] = the gradient at T_out; wave_keys as in se3mpc_rollout_cost_grad_*.
+ * Multi-batch (grid.y): operands as in se3mpc_rollout_cost_grad_batched_* with T_out / cost_first laid out like T / cost.
+ * se3mpc_projected_step_* is one descent step as its own launch (T_out = clip(T - step * gradT)): iterating
+ * se3mpc_rollout_cost_grad_* + se3mpc_projected_step_* from the host is what this entry point replaces. */
+int se3mpc_rollout_iterate_f32(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const float* p0,
+                               const float* v0, const float* goal, const float* T_in, float* T_out, float* cost_first, float* cost,
+                               float* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream);
+int se3mpc_rollout_iterate_f64(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const double* p0,
+                               const double* v0, const double* goal, const double* T_in, double* T_out, double* cost_first, double* cost,
+                               double* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream);
+int se3mpc_projected_step_f32(const se3mpc_params* p, int B, int ld, double step, const float* T, const float* gradT, float* T_out,
+                              void* stream);
+int se3mpc_projected_step_f64(const se3mpc_params* p, int B, int ld, double step, const double* T, const double* gradT, double* T_out,
+                              void* stream);
+
 /* keys_out[i] = min over wave_keys[i][0..per_batch) for i < nbatch (one small workgroup per batch). */
 int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uint64_t* keys_out, void* stream);
 

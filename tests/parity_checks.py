@@ -222,6 +222,91 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
     assert np.array_equal(h.to_host(Xt), X.astype(h.dt).T)
 
 
+def thrust_box(cfg):
+    txy = cfg.max_thrust * np.sin(cfg.max_tilt_angle)
+    return np.array([-txy, -txy, cfg.min_thrust]), np.array([txy, txy, cfg.max_thrust])
+
+
+def oracle_iterate(p0, v0, goal, T, cfg, iters, step):
+    """Host-chained float64 reference of se3mpc_rollout_iterate_*: `iters` x (rollout + cost + gradient, projected step), one last
+    evaluation.  -> T_final, cost_final, grad_final, cost_first"""
+    lo, hi = thrust_box(cfg)
+    T = np.array(T, dtype=float)
+    c0 = None
+    for _ in range(iters):
+        c, g = orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+        c0 = c if c0 is None else c0
+        T = np.clip(T - step * g, lo, hi)
+    c, g = orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+    return T, c, g, (c if c0 is None else c0)
+
+
+def check_rollout_iterate(h: Harness, N: int, B: int, seed: int = 0, iters: int = 5, step: float = 0.9):
+    """The on-device iteration loop: (1) against the host-chained oracle; (2) K iterations in one launch == K launches of one
+    iteration, bit for bit (the thrust sequence crosses HBM between launches, stays in registers inside one); (3) == the chain
+    se3mpc_rollout_cost_grad + se3mpc_projected_step it replaces; (4) iters = 0 == the plain rollout; (5) multi-batch launch ==
+    batch by batch; (6) the fused argmin key; (7) the descent really descends."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N)
+    cfg = oracle_cfg(prm)
+    t = h.tol
+    p0, v0, goal, T = random_batch(rng, B, N, spread=6.0)          # wide spread: some thrusts start outside the box
+    r = lambda a: np.asarray(a).astype(h.dt).astype(float)
+    Tr, cr, gr, c0r = oracle_iterate(r(p0), r(v0), r(goal), r(T), cfg, iters, step)
+    lp0, lv0, lg, lT = h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B)
+    key = h.to_dev(np.zeros((B + 63) // 64, dtype=np.int64))
+    out = h.ops.rollout_iterate(prm, lp0, lv0, lg, lT, iters, step, want_first_cost=True, wave_keys=key, index_base=40)
+    Tk = h.unlane(out["T"], (B, N, 3))
+    scale = 50.0 if h.dt == np.float32 else 1.0                    # f32: `iters` descent steps amplify one-ulp differences of the gradient
+    vec_close(Tk, Tr, t["vec_rel"] * scale, "iterated T")
+    ch = h.to_host(out["cost"]).astype(float)
+    assert np.max(np.abs(ch - cr) / np.abs(cr)) <= t["cost_rel"] * scale, "iterated cost"
+    vec_close(h.unlane(out["gradT"], (B, N, 3)), gr, t["vec_rel"] * scale, "gradient at the final T")
+    assert np.max(np.abs(h.to_host(out["cost_first"]).astype(float) - c0r) / np.abs(c0r)) <= t["cost_rel"], "cost at T_in"
+    lo, hi = thrust_box(cfg)
+    assert np.all(Tk >= lo.astype(h.dt).astype(float) - 0) and np.all(Tk <= hi.astype(h.dt).astype(float) + 0), "box"
+    assert np.all(ch <= h.to_host(out["cost_first"]).astype(float) * (1 + 1e-6)), "descent"                      # (7)
+    kd = h.to_dev(np.zeros(1, dtype=np.int64))
+    h.ops.reduce_keys(key.reshape(1, -1), kd)
+    idx, kc = h.ops.decode_key(kd)
+    assert idx == 40 + int(np.argmin(h.to_host(out["cost"]))) and kc == np.float32(h.to_host(out["cost"]).min())   # (6)
+    # (2) one launch == `iters` launches of one iteration
+    Tc = lT
+    for _ in range(iters):
+        Tc = h.ops.rollout_iterate(prm, lp0, lv0, lg, Tc, 1, step, want_grad=False)["T"]
+    last = h.ops.rollout_iterate(prm, lp0, lv0, lg, Tc, 0, step)
+    assert np.array_equal(h.to_host(Tc), h.to_host(out["T"])), "K iterations in one launch != K one-iteration launches"
+    assert np.array_equal(h.to_host(last["cost"]), h.to_host(out["cost"])) and np.array_equal(h.to_host(last["gradT"]), h.to_host(out["gradT"]))
+    assert np.array_equal(h.to_host(last["T"]), h.to_host(Tc))
+    # (3) the chain of the two stand-alone launches this entry point replaces
+    Th = lT
+    for _ in range(iters):
+        _, g1, _, _ = h.ops.rollout_cost_grad(prm, lp0, lv0, lg, Th)
+        Th = h.ops.projected_step(prm, Th, g1, step)
+    c2, g2, _, _ = h.ops.rollout_cost_grad(prm, lp0, lv0, lg, Th)
+    bitwise = np.array_equal(h.to_host(Th), h.to_host(out["T"]))
+    vec_close(h.to_host(Th), h.to_host(out["T"]).astype(float), 2e-6 if h.dt == np.float32 else 1e-13, "host chain vs one launch")
+    assert np.allclose(h.to_host(c2), h.to_host(out["cost"]), rtol=2e-6 if h.dt == np.float32 else 1e-13, atol=0)
+    # (4) iters = 0
+    o0 = h.ops.rollout_iterate(prm, lp0, lv0, lg, lT, 0, step)
+    c1, g1, _, _ = h.ops.rollout_cost_grad(prm, lp0, lv0, lg, lT)
+    assert np.array_equal(h.to_host(o0["T"]), h.to_host(lT))
+    assert np.allclose(h.to_host(o0["cost"]), h.to_host(c1), rtol=t["cost_rel"], atol=0)
+    vec_close(h.to_host(o0["gradT"]), h.to_host(g1).astype(float), t["vec_rel"], "iters = 0 gradient")
+    # (5) multi-batch launch, in place (T_out = T)
+    nb = 3
+    rngb = np.random.default_rng(seed + 7)
+    bp0, bv0, bgoal, bT = (np.stack(x) for x in zip(*[random_batch(rngb, B, N) for _ in range(nb)]))
+    st = lambda a, rows: h.to_dev(np.ascontiguousarray(np.transpose(a.reshape(nb, B, rows), (0, 2, 1)).astype(h.dt)))
+    dp0, dv0, dgoal, dT = st(bp0, 3), st(bv0, 3), st(bgoal, 3), st(bT, 3 * N)
+    ob = h.ops.rollout_iterate(prm, dp0, dv0, dgoal, dT, iters, step, T_out=dT)
+    for i in range(nb):
+        oi = h.ops.rollout_iterate(prm, h.lane(bp0[i], B), h.lane(bv0[i], B), h.lane(bgoal[i], B), h.lane(bT[i], B), iters, step)
+        for nm in ("T", "cost", "gradT"):
+            assert np.array_equal(h.to_host(ob[nm])[i], h.to_host(oi[nm])), ("batched iterate", nm)
+    return bitwise
+
+
 def check_key_nonfinite(h: Harness):
     """Packed argmin keys with non-finite costs: NaN of either sign must never win (a negative NaN would sort below
     -inf in a plain sign-magnitude map) nor pass for the dead-lane sentinel; -inf wins over everything real; +inf

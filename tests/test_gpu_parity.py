@@ -48,6 +48,42 @@ def test_population_sums(gpu_ops, dt, rows, B):
     pc.check_population_sums(harness(gpu_ops, dt), rows=rows, B=B, seed=rows)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(6, 300), (20, 257), (30, 1000), (50, 129), (7, 9), (24, 130), (64, 65), (1, 5)])
+def test_rollout_iterate(gpu_ops, dt, N, B):
+    bitwise = pc.check_rollout_iterate(harness(gpu_ops, dt), N, B, seed=N, iters=6)
+    print(f"N={N} {np.dtype(dt).name}: one launch vs rollout_cost_grad + projected_step chain bit-identical: {bitwise}")
+
+
+def test_rollout_iterate_full_size(gpu_ops):
+    """The metric's own batch (N = 30, B = 8192): 16 iterations in one launch == 16 one-iteration launches bit for bit, a 256-trajectory
+    sample against the host-chained oracle, every trajectory inside the box and no worse than where it started."""
+    import torch
+    from dart_planner_amd.capi import Params
+    ops = gpu_ops
+    dev = ops.be.device
+    N, B, K, step = 30, 8192, 16, 0.9
+    prm = Params.reference_defaults(horizon=N)
+    g = torch.Generator(device=dev); g.manual_seed(1)
+    p0 = torch.rand(3, B, device=dev, generator=g) * 40 - 20
+    v0 = torch.rand(3, B, device=dev, generator=g) * 10 - 5
+    goal = torch.rand(3, B, device=dev, generator=g) * 40 - 20
+    T = torch.randn(3 * N, B, device=dev, generator=g) * 2
+    T[2::3] += 14.715
+    out = ops.rollout_iterate(prm, p0, v0, goal, T, K, step, want_first_cost=True)
+    Tc = T
+    for _ in range(K):
+        Tc = ops.rollout_iterate(prm, p0, v0, goal, Tc, 1, step, want_grad=False)["T"]
+    assert torch.equal(Tc, out["T"])
+    assert bool((out["cost"] <= out["cost_first"] * (1 + 1e-6)).all())
+    cfg = orc.OracleConfig(prediction_horizon=N)
+    pick = np.random.default_rng(0).choice(B, 256, replace=False)
+    hst = lambda a: a[:, pick].double().cpu().numpy().T
+    Tr, cr, gr, _ = pc.oracle_iterate(hst(p0), hst(v0), hst(goal), hst(T).reshape(256, N, 3), cfg, K, step)
+    assert np.max(np.abs(hst(out["T"]).reshape(256, N, 3) - Tr)) <= 2e-4
+    assert np.max(np.abs(out["cost"][pick].cpu().numpy() - cr) / cr) <= 5e-5
+
+
 def test_keys_with_nonfinite_costs(gpu_ops):
     pc.check_key_nonfinite(harness(gpu_ops, np.float32))
 
