@@ -650,8 +650,12 @@ __device__ __forceinline__ R projected_update(R t, R g, R step, R lo, R hi) {
 template <typename R, int N, bool EXACT, int LDAUX, int STAUX>
 __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
-                                              R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, R& cost_first) {
-  // `live`: tail lanes shadow the last trajectory (identical loads) but must not store -- Tout may alias Tin
+                                              R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, bool want_first,
+                                              R& cost_first) {
+  // `live`: tail lanes shadow the last trajectory (identical loads) but must not store -- Tout may alias Tin.
+  // The sweeps come in two flavours so that the iterations in between carry no dead weight: the descent iterations roll out the
+  // states only (no cost sums) and consume the gradient in place; cost sums and gradient stores exist only in the evaluation
+  // passes (the optional one at T_in and the last one).
   const int Nn = EXACT ? N : q.N;
   R t[N], es[N], vs[N];
 #pragma unroll
@@ -662,10 +666,8 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
   const R pinit = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
   const R vinit = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
   const R lo = (a == 2) ? q.tz_lo : -q.txy, hi = (a == 2) ? q.tz_hi : q.txy;      // planner.py:390-400
-  R cost = (R)0;
-#pragma unroll 1
-  for (int it = 0; it <= iters; ++it) {
-    const bool last = it == iters;
+  // forward sweep with the cost sums (evaluation passes)
+  auto forward_cost = [&]() -> R {
     R p = pinit, v = vinit;
     RolloutSums<R> s = {0, 0, 0, 0, 0};
 #pragma unroll
@@ -682,8 +684,46 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
       }
     }
     s.sp += s.sterm;
-    cost = axis_cost(q, s);
-    if (it == 0) cost_first = cost;
+    return axis_cost(q, s);
+  };
+  cost_first = (R)0;
+  if (want_first && iters > 0) cost_first = forward_cost();
+#pragma unroll 1
+  for (int it = 0; it < iters; ++it) {
+    R p = pinit, v = vinit;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {                              // states only
+      if (EXACT || k < Nn) {
+        const R acc = t[k] * q.inv_mass - c.grav;
+        es[k] = p - c.gl; vs[k] = v;
+        p = p + v * q.dt + q.half_dt2 * acc;
+        v = v + acc * q.dt;
+      }
+    }
+    R lamP = (R)0, lamV = (R)0;
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {                          // adjoint sweep; T_k is overwritten as soon as g_k exists
+      if (EXACT || k < Nn) {
+        const R acc = t[k] * q.inv_mass - c.grav;
+        const R dev = t[k] - c.hov;
+        R g;
+        if (k == Nn - 1) {
+          g = c.c_aa * acc + c.c_tt * dev;
+          lamP = c.two_wp * ((R)1 + q.term) * es[k];
+          lamV = c.two_wv * vs[k];
+        } else {
+          g = c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV;
+          lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
+          lamP = c.two_wp * es[k] + lamP;
+        }
+        t[k] = projected_update(t[k], g, step, lo, hi);
+      }
+    }
+  }
+  // the last evaluation: cost and gradient at the final T (the gradient parks in the state registers it has just consumed)
+  const R cost = forward_cost();
+  if (!(want_first && iters > 0)) cost_first = cost;
+  if (gradT != nullptr) {
     R lamP = (R)0, lamV = (R)0;
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {
@@ -700,17 +740,21 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
           lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
           lamP = c.two_wp * es[k] + lamP;
         }
-        if (last) {
-          if (gradT != nullptr && live) lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, g);
-        } else {
-          t[k] = projected_update(t[k], g, step, lo, hi);
-        }
+        es[k] = g;
       }
     }
   }
+  if (live) {
+    if (gradT != nullptr) {
 #pragma unroll
-  for (int k = 0; k < N; ++k) {
-    if ((EXACT || k < Nn) && live) lane_st<STAUX>(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, t[k]);
+      for (int k = 0; k < N; ++k) {
+        if (EXACT || k < Nn) lane_st<STAUX>(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, es[k]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+      if (EXACT || k < Nn) lane_st<STAUX>(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, t[k]);
+    }
   }
   return cost;
 }
@@ -720,7 +764,9 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
 template <typename R>
 __device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
-                                              R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, R& cost_first) {
+                                              R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, bool want_first,
+                                              R& cost_first) {
+  (void)want_first;
   // the working copy lives in Tout, so a tail lane has nothing of its own to iterate on: it leaves (no cross-lane op below)
   if (!live) { cost_first = (R)0; return (R)0; }
   const int N = q.N;
@@ -802,8 +848,8 @@ rollout_iterate_kernel(DevParams<R> q, int B, int ld, int iters, R step, const R
   __shared__ R part[2][3][kWave];
   const int a = wave_uniform((int)(threadIdx.x / kWave));
   R c0 = (R)0, c;
-  if constexpr (REG) c = iterate_axis_reg<R, N, !(FLAGS & 8), (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, c0);
-  else c = iterate_axis_mem<R>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, c0);
+  if constexpr (REG) c = iterate_axis_reg<R, N, !(FLAGS & 8), (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0);
+  else c = iterate_axis_mem<R>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0);
   part[0][a][lane] = c; part[1][a][lane] = c0;
   __syncthreads();
   const R total = part[0][0][lane] + part[0][1][lane] + part[0][2][lane];
