@@ -214,7 +214,12 @@ class DeviceVoxelMap:
         if M == 0:
             return 0, len(self)
         max_len = 3 * int(np.ceil(float(np.max(dist)) / self.resolution)) + 8
-        self.reserve(int(np.sum(3 * np.ceil(dist / self.resolution) + 8)))       # every walked voxel could be new
+        # Validate BEFORE the first launch, so a scan is applied whole or not at all (the reference's dict never fails): every voxel a
+        # ray can walk lies within one cell of the box spanned by its end points, which must stay inside the packable index range.
+        ends = np.concatenate([o, o + d * dist[:, None]]) / self.resolution
+        if not np.all(np.isfinite(ends)) or np.max(np.abs(ends)) >= (1 << 20) - 2:
+            raise ValueError("a ray leaves the packable voxel index range (|index| < 2^20); nothing was applied")
+        per_ray = 3 * np.ceil(dist / self.resolution) + 8                        # every walked voxel could be new
         chunk = min(M, 1024)
         while chunk > 64 and self.lib.voxel_update_row_words(chunk, max_len) * 8 > (256 << 20):
             chunk //= 2                                                            # keep the bit-set workspace under 256 MiB
@@ -228,6 +233,7 @@ class DeviceVoxelMap:
         for lo in range(0, M, chunk):
             hi = min(M, lo + chunk)
             n = hi - lo
+            self.reserve(int(np.sum(per_ray[lo:hi])))                            # per chunk: a long scan does not size the table for all its rays at once
             # one upload per chunk: [origin 3n | direction 3n | distance n] float64, then hit n int32
             packed = np.empty(7 * n * 8 + n * 4, dtype=np.uint8)
             f64 = packed[:7 * n * 8].view(np.float64)
@@ -240,7 +246,9 @@ class DeviceVoxelMap:
                            self.be.ptr(self._slot_rows), self.be.ptr(self._row_bits), self.be.ptr(stats), self.be.stream())
             st = self.be.to_host(stats)
             if int(st[1]) or int(st[2]):
-                raise RuntimeError(f"voxel update dropped work: {int(st[1])} voxels not stored, {int(st[2])} rays truncated")
+                self._n = None                                                    # recount from the device on the next len()
+                raise RuntimeError(f"voxel update dropped work: {int(st[1])} voxels not stored, {int(st[2])} rays truncated "
+                                   f"(chunk {lo}:{hi}; earlier chunks are applied)")
             updates += int(st[0])
             if self._n is not None:
                 self._n += int(st[3])

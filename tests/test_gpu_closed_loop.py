@@ -209,3 +209,49 @@ def test_monte_carlo_f32_tracks_f64(gpu_ops):
     err = (r32[0].double() - r64[0]).abs().max(dim=1).values
     print(f"f32 vs f64 Monte-Carlo end positions: median {float(err.median()):.2e} m, 95 % {float(err.quantile(0.95)):.2e} m, max {float(err.max()):.2e} m")
     assert float(err.median()) <= 5e-3 and float(err.quantile(0.95)) <= 0.25
+
+
+# ------------------------------------------------------------------ f-3: a device-solved plan on the wire
+def _reference_envelope_verify(raw: bytes, secret: str):
+    """The receiving side of the reference's envelope, restated from its rules
+    (/root/reference/src/dart_planner/communication/secure_serializer.py:92-167): the message is JSON with exactly the fields
+    (data, signature, timestamp, message_id); the signature is HMAC-SHA256(secret, f"{json.dumps(data)}:{timestamp}:{message_id}")
+    as lowercase hex, where `data` is re-dumped from the PARSED message with json's default separators.  Returns data."""
+    import hashlib
+    import hmac
+    msg = json.loads(raw.decode("utf-8"))
+    assert set(msg) == {"data", "signature", "timestamp", "message_id"}
+    expect = hmac.new(secret.encode("utf-8"), f"{json.dumps(msg['data'])}:{msg['timestamp']}:{msg['message_id']}".encode("utf-8"),
+                      hashlib.sha256).hexdigest()
+    assert hmac.compare_digest(msg["signature"], expect), "signature"
+    return msg["data"]
+
+
+def test_device_plan_travels_in_the_reference_envelope(gpu_ops):
+    """Plan on the MI355X, put the Trajectory on the wire with this package's SecureSerializer, and check the bytes with a verifier
+    written from the reference's envelope rules -- a verifier that is first proven on messages the reference's own serializer signed
+    (tests/golden/wire_messages.json) and on tampered copies of them."""
+    from dart_planner_amd.common.types import DroneState
+    from dart_planner_amd.communication.secure_serializer import SecureSerializer, trajectory_from_wire
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCPlanner
+    g = json.load(open(os.path.join(GOLDEN, "wire_messages.json")))
+    for m in g["messages"]:                                   # the verifier accepts what the reference signed ...
+        raw = m["raw"].encode("utf-8")
+        _reference_envelope_verify(raw, g["secret"])
+        bad = raw.replace(b'"timestamp": ', b'"timestamp": 1', 1)
+        with pytest.raises(AssertionError):                   # ... and rejects a tampered copy and a wrong key
+            _reference_envelope_verify(bad, g["secret"])
+        with pytest.raises(AssertionError):
+            _reference_envelope_verify(raw, g["secret"] + "x")
+    pl = SE3MPCPlanner(precision="f64")
+    tr = pl.plan_trajectory(DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.zeros(3)), np.array([5.0, 3.0, 2.0]))
+    assert pl._get_ops().lib.path.endswith("libse3mpc.so") and pl.last_result["nfev"] == 3
+    ser = SecureSerializer(secret_key=g["secret"], message_ttl=300)
+    raw = ser.serialize({"status": "ok", "trajectory": tr})                      # the cloud handler's reply (cloud/main_improved.py:87)
+    data = _reference_envelope_verify(raw, g["secret"])
+    back = trajectory_from_wire(data["trajectory"])
+    for f in ("timestamps", "positions", "velocities", "accelerations", "attitudes", "body_rates", "thrusts", "yaws", "yaw_rates"):
+        assert np.array_equal(np.asarray(getattr(back, f)), np.asarray(getattr(tr, f))), f     # repr round trip of float64: exact
+    assert np.max(np.abs(back.positions[0] - [2.1897985430479023, 2.1897985430479023, 3.1679005576174233])) <= 1e-9   # SURVEY Appendix B
+    # and this package's own receiving side agrees
+    assert np.array_equal(trajectory_from_wire(ser.deserialize(raw)["trajectory"]).positions, tr.positions)
