@@ -224,8 +224,6 @@ class DeviceVoxelMap:
         while chunk > 64 and self.lib.voxel_update_row_words(chunk, max_len) * 8 > (256 << 20):
             chunk //= 2                                                            # keep the bit-set workspace under 256 MiB
         words = self.lib.voxel_update_row_words(chunk, max_len)
-        if self._row_bits is None or int(np.prod(self._row_bits.shape)) < words:
-            self._row_bits = self._zeros((words,), "i64")
         ray_keys = self.be.empty((chunk, max_len), "i64")
         ray_len = self.be.empty((chunk,), "i32")
         stats = self.be.empty((4,), "i32")
@@ -234,6 +232,8 @@ class DeviceVoxelMap:
             hi = min(M, lo + chunk)
             n = hi - lo
             self.reserve(int(np.sum(per_ray[lo:hi])))                            # per chunk: a long scan does not size the table for all its rays at once
+            if self._row_bits is None or int(np.prod(self._row_bits.shape)) < words:   # (a re-hash drops the workspace)
+                self._row_bits = self._zeros((words,), "i64")
             # one upload per chunk: [origin 3n | direction 3n | distance n] float64, then hit n int32
             packed = np.empty(7 * n * 8 + n * 4, dtype=np.uint8)
             f64 = packed[:7 * n * 8].view(np.float64)
