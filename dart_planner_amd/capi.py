@@ -205,6 +205,7 @@ _PLAIN_API = {
     "se3mpc_default_params": (C.c_int, [_PP]),
     "se3mpc_check_params": (C.c_int, [_PP]),
     "se3mpc_set_rollout_variant": (C.c_int, [_I]),
+    "se3mpc_set_solver_variant": (C.c_int, [_I]),
     "se3mpc_reduce_keys": (C.c_int, [_P, _I, _I, _P, _P]),
     "se3mpc_key_index": (C.c_uint32, [C.c_uint64]),
     "se3mpc_key_cost": (C.c_float, [C.c_uint64]),
@@ -286,6 +287,9 @@ class Library:
 
     def set_rollout_variant(self, variant: int) -> None:
         self._check("se3mpc_set_rollout_variant", self._dll.se3mpc_set_rollout_variant(variant))
+
+    def set_solver_variant(self, variant: int) -> None:
+        self._check("se3mpc_set_solver_variant", self._dll.se3mpc_set_solver_variant(variant))
 
     def reduce_keys(self, wave_keys: int, per_batch: int, nbatch: int, keys_out: int, stream: int) -> None:
         self._check("se3mpc_reduce_keys", self._dll.se3mpc_reduce_keys(wave_keys, per_batch, nbatch, keys_out, stream))

@@ -28,7 +28,7 @@ constexpr double kBig = 1.0e10;
 constexpr double kInf = __builtin_huge_val();
 
 struct SolveDev {
-  int N, n, has_goal, m, mlds, only_overflow, maxiter, maxls, maxfun;
+  int N, n, has_goal, m, mlds, only_overflow, maxiter, maxls, maxfun, seq_cauchy;
   double dt, mass, grav, hover, wp, wv, wa, wT, term;
   double pos_b, v_max, txy, tz_lo, tz_hi;
   double pgtol, ftol;
@@ -37,7 +37,7 @@ struct SolveDev {
 static SolveDev make_solve_dev(const se3mpc_params& p) {
   SolveDev d;
   d.N = p.horizon; d.n = 9 * p.horizon; d.has_goal = p.has_goal; d.m = p.max_corrections;
-  d.mlds = p.max_corrections; d.only_overflow = 0;
+  d.mlds = p.max_corrections; d.only_overflow = 0; d.seq_cauchy = 0;
   d.maxiter = p.max_iterations; d.maxls = p.max_linesearch; d.maxfun = p.max_fun;
   d.dt = p.dt; d.mass = p.mass; d.grav = p.gravity; d.hover = p.mass * p.gravity;
   d.wp = p.position_weight; d.wv = p.velocity_weight; d.wa = p.acceleration_weight; d.wT = p.thrust_weight;
@@ -421,7 +421,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         }
         z[j] = x[j];
       }
-      if (col == 0) {
+      if (col == 0 && !q.seq_cauchy) {
         // No L-BFGS pairs yet: B = theta*I and the piecewise quadratic along the projected path is
         //   m(t) = sum_i g_i^2 (theta*tau_i^2/2 - tau_i),  tau_i = min(t, t_i),
         // whose derivative sum_{t_i > t} g_i^2 (theta*t - 1) is negative on [0, 1/theta): the sequential
@@ -893,6 +893,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   }
 }
 
+static int g_solver_variant = 0;   // bit 0: published sequential Cauchy search also while the memory is empty
+
 static size_t solve_lds_bytes(int m, int J, size_t io_size) {
   const size_t doubles = (size_t)3 * m * m + 4 * m * m + 5 * 2 * m + 8 + (size_t)kWave * J;
   size_t pairs = (size_t)2 * m * kWave * J * io_size;
@@ -911,6 +913,7 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !X || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
   SolveDev q = make_solve_dev(*p);
+  q.seq_cauchy = g_solver_variant & 1;
   const int n = q.n;
   const int Jneed = (n + kWave - 1) / kWave;
   hipStream_t s = (hipStream_t)stream;
@@ -944,6 +947,12 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
 }  // namespace se3mpc
 
 using namespace se3mpc;
+
+extern "C" int se3mpc_set_solver_variant(int variant) {
+  if (variant < 0 || variant > 1) return SE3MPC_ERR_SHAPE;
+  se3mpc::g_solver_variant = variant;
+  return SE3MPC_OK;
+}
 
 extern "C" int se3mpc_solve_f32(const se3mpc_params* p, int B, const float* p0, const float* v0, const float* goal,
                                 const float* x0, float* X, se3mpc_solve_info* info, float* acc, float* att,

@@ -492,6 +492,15 @@ int se3mpc_closed_loop_f64(const se3mpc_controller_params* cp, const se3mpc_simu
  *   acc, att, rates : [B][N][3], thrust : [B][N]   (any may be NULL)
  * All accumulations that feed a branch of L-BFGS-B run in double; `_f32` keeps the vectors in
  * float. */
+/* Which generalized-Cauchy-point search se3mpc_solve_* runs while the L-BFGS memory is empty (B = theta I: the first iterate of every
+ * solve and every iterate after a memory refresh).  0 (default): the closed form -- with B = theta I the published search crosses
+ * exactly the breakpoints t_i <= 1/theta and stops at t = 1/theta, so the point is the projected step P(x - g/theta), one parallel
+ * pass.  1: the published sequential breakpoint search (Byrd-Lu-Nocedal-Zhu 1995, algorithm CP) everywhere, as SciPy's L-BFGS-B
+ * runs it: same iterates up to the rounding of its accumulated dtm = -f1/f2 (1e-8 N on thrust entries when nearly all of sum g^2
+ * sits on variables that reach their bounds), ~5x slower on the first iterate.  With 1 the f64 solve reproduces the reference's
+ * thrust block to 1e-9. */
+int se3mpc_set_solver_variant(int variant);
+
 int se3mpc_solve_f32(const se3mpc_params* p, int B, const float* p0, const float* v0, const float* goal,
                      const float* x0, float* X, se3mpc_solve_info* info, float* acc, float* att,
                      float* rates, float* thrust, void* stream);

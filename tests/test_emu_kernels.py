@@ -60,6 +60,19 @@ def test_solver_reproduces_reference_solves(emu_ops, golden_solve, dt):
     assert worst <= (1e-4 if dt == np.float32 else 1e-9)
 
 
+def test_solver_published_cauchy_search(emu_ops, golden_solve):
+    """se3mpc_set_solver_variant(1): the published sequential breakpoint search everywhere (no closed form while the memory is empty).
+    Same counts as the reference on every golden solve, and the f64 thrust block to 1e-9 -- the 1e-7 carve-out of the default path
+    (closed-form Cauchy point) is not needed."""
+    data, meta = golden_solve
+    emu_ops.lib.set_solver_variant(1)
+    try:
+        worst = pc.check_solver_golden(harness(emu_ops, np.float64), data, meta, thrust_tol=1e-9)
+    finally:
+        emu_ops.lib.set_solver_variant(0)
+    assert worst <= 1e-9
+
+
 def test_solver_config1_sample(emu_ops, golden_cfg1):
     data, meta = golden_cfg1
     two_its = [int(i) for i in np.nonzero(data["info"][:, 0] != 1)[0]]          # the one solve that takes two iterations

@@ -102,6 +102,22 @@ def test_solver_reproduces_every_reference_solve(gpu_ops, golden_solve, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_published_cauchy_search(gpu_ops, golden_solve, golden_cfg1, dt):
+    """se3mpc_set_solver_variant(1): the published sequential Cauchy search everywhere.  Every golden solve again, f64 thrust block
+    held to 1e-9 (no carve-out), config 1's set, and a batch against SciPy."""
+    data, meta = golden_solve
+    gpu_ops.lib.set_solver_variant(1)
+    try:
+        worst = pc.check_solver_golden(harness(gpu_ops, dt), data, meta, thrust_tol=1e-9 if dt == np.float64 else None)
+        assert worst <= (1e-4 if dt == np.float32 else 1e-9)
+        pc.check_solver_cfg1(harness(gpu_ops, dt), *golden_cfg1)
+        w, mism = pc.check_solver_vs_oracle(harness(gpu_ops, dt), 30, 128, seed=2)
+        assert w <= (1e-4 if dt == np.float32 else 1e-9) and mism <= (0.0 if dt == np.float64 else 0.02)
+    finally:
+        gpu_ops.lib.set_solver_variant(0)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_solver_config1_exact_problem_set(gpu_ops, golden_cfg1, dt):
     """BASELINE.json config 1: all 101 reference solves of the horizon-20 / |v| <= 8 configuration in one launch."""
     data, meta = golden_cfg1
