@@ -41,119 +41,159 @@ __device__ __forceinline__ LaneIdx lane_index(int B) {
 // a3 + a4: cold start (planner.py:329-359) and optional projection into the box (:378-402)
 // ------------------------------------------------------------------------------------------
 template <typename R>
-__global__ void init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
-                            const R* __restrict__ goal, int project, R* __restrict__ X) {
-  const LaneIdx li = lane_index<R>(B);
-  if (!li.live) return;
-  const int b = li.b;
-  (void)b;
-  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
+__global__ void __launch_bounds__(192)
+init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
+            const R* __restrict__ goal, int project, R* __restrict__ X) {
+  // write-only stream: a 192-thread workgroup owns 64 trajectories, wavefront w writes axis w (3x the wavefronts in flight)
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int b0 = blk * kWave + (int)(threadIdx.x & (kWave - 1));
+  if (b0 >= B) return;
+  const unsigned voff = (unsigned)b0 * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
   const int N = q.N, N3 = 3 * q.N;
   const R denom = (R)(N - 1 > 1 ? N - 1 : 1);
-  for (int a = 0; a < 3; ++a) {
-    const R p = lane_ld<2>(lane_buf(p0), voff, (unsigned)(a) * rowb);
-    const R v = lane_ld<2>(lane_buf(v0), voff, (unsigned)(a) * rowb);
-    const R g = q.has_goal ? lane_ld<2>(lane_buf(goal), voff, (unsigned)(a) * rowb) : p;
-    R prev = p;
-    for (int i = 0; i < N; ++i) {
-      R pi, vi;
-      if (q.has_goal) {
-        const R alpha = (R)i / denom;                       // planner.py:344
-        pi = ((R)1 - alpha) * p + alpha * g;                // planner.py:345-347
-        if constexpr (sizeof(R) == 4) {
-          // float32: (P_i - P_{i-1})/dt loses ~|P| * 6e-8 / dt ~ 1e-3 m/s to cancellation; the
-          // algebraically identical (alpha_i - alpha_{i-1}) (goal - p0) / dt does not
-          vi = (i == 0) ? v : ((alpha - (R)(i - 1) / denom) * (g - p)) / q.dt;
-        } else {
-          vi = (i == 0) ? v : (pi - prev) / q.dt;           // planner.py:339, :350
-        }
+  const R p = lane_ld<2>(lane_buf(p0), voff, (unsigned)(a) * rowb);
+  const R v = lane_ld<2>(lane_buf(v0), voff, (unsigned)(a) * rowb);
+  const R g = q.has_goal ? lane_ld<2>(lane_buf(goal), voff, (unsigned)(a) * rowb) : p;
+  R prev = p;
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    R pi, vi;
+    if (q.has_goal) {
+      const R alpha = (R)i / denom;                       // planner.py:344
+      pi = ((R)1 - alpha) * p + alpha * g;                // planner.py:345-347
+      if constexpr (sizeof(R) == 4) {
+        // float32: (P_i - P_{i-1})/dt loses ~|P| * 6e-8 / dt ~ 1e-3 m/s to cancellation; the
+        // algebraically identical (alpha_i - alpha_{i-1}) (goal - p0) / dt does not
+        vi = (i == 0) ? v : ((alpha - (R)(i - 1) / denom) * (g - p)) / q.dt;
       } else {
-        pi = p;                                             // planner.py:356
-        vi = (i == 0) ? v : (R)0;
+        vi = (i == 0) ? v : (pi - prev) / q.dt;           // planner.py:339, :350
       }
-      prev = pi;
-      R ti = (a == 2) ? q.hover : (R)0;                     // planner.py:353
-      if (project) {
-        pi = fmin(fmax(pi, -q.pos_b), q.pos_b);
-        vi = fmin(fmax(vi, -q.v_max), q.v_max);
-        ti = (a == 2) ? fmin(fmax(ti, q.tz_lo), q.tz_hi) : ti;
-      }
-      lane_st<2>(lane_buf(X), voff, (unsigned)(3 * i + a) * rowb, (R)(pi));
-      lane_st<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * i + a) * rowb, (R)(vi));
-      lane_st<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * i + a) * rowb, (R)(ti));
+    } else {
+      pi = p;                                             // planner.py:356
+      vi = (i == 0) ? v : (R)0;
     }
+    prev = pi;
+    R ti = (a == 2) ? q.hover : (R)0;                     // planner.py:353
+    if (project) {
+      pi = fmin(fmax(pi, -q.pos_b), q.pos_b);
+      vi = fmin(fmax(vi, -q.v_max), q.v_max);
+      ti = (a == 2) ? fmin(fmax(ti, q.tz_lo), q.tz_hi) : ti;
+    }
+    lane_st<2>(lane_buf(X), voff, (unsigned)(3 * i + a) * rowb, (R)(pi));
+    lane_st<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * i + a) * rowb, (R)(vi));
+    lane_st<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * i + a) * rowb, (R)(ti));
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // a5 + a6: objective (planner.py:516-550) and the reference's gradient (planner.py:552-580)
 // ------------------------------------------------------------------------------------------
-template <typename R>
-__global__ void __launch_bounds__(64)
+// Streaming shape shared by the parity-form kernels below: a 192-thread workgroup owns 64 trajectories and
+// wavefront w works on axis w wherever the arithmetic is separable per axis; rows are taken in chunks of kChunk steps whose loads
+// are ALL issued before the first use (3 * kChunk independent HBM requests in flight per lane, the same memory-level parallelism the
+// benchmarked rollout kernel gets from its register arrays), then consumed and stored.  Per-row loops with a load -> use -> store
+// dependence per step reached 55-63 % of the HBM peak; this shape reaches the copy ceiling of the part.
+constexpr int kChunk = 16;
+
+template <typename R, bool WANT_G>
+__global__ void __launch_bounds__(192)
 cost_grad_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, const R* __restrict__ goal,
                  R* __restrict__ f, R* __restrict__ g) {
-  const LaneIdx li = lane_index<R>(B);
-  const bool live = li.live;
-  const int b = li.b;                                       // tail lanes shadow the last column (benign duplicate stores)
-  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
+  __shared__ R part[3][kWave];
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int b0 = blk * kWave + lane;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;                          // tail lanes shadow the last column (benign duplicate stores)
+  const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
   const int N = q.N, N3 = 3 * q.N;
   const LaneBuf<R> xb = lane_buf(X), gb = lane_buf(g);
+  const R gl = q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)a * rowb) : (R)0;
+  const R grav = (a == 2) ? q.grav : (R)0;
+  const R hov = (a == 2) ? q.hover : (R)0;
+  const R two_wp = q.has_goal ? (R)2 * q.wp : (R)0, two_wv = (R)2 * q.wv, two_wT = (R)2 * q.wT;
   R sp = 0, sv = 0, sa = 0, st = 0, sterm = 0;
-  for (int a = 0; a < 3; ++a) {
-    const R gl = q.has_goal ? goal[(size_t)a * ld + b] : (R)0;
-    const R grav = (a == 2) ? q.grav : (R)0;
-    const R hov = (a == 2) ? q.hover : (R)0;
-#pragma unroll 6
-    for (int k = 0; k < N; ++k) {
-      const unsigned rp = (unsigned)(3 * k + a) * rowb, rv = (unsigned)(N3 + 3 * k + a) * rowb,
-                     rt = (unsigned)(2 * N3 + 3 * k + a) * rowb;
-      const R x = lane_ld<2>(xb, voff, rp), v = lane_ld<2>(xb, voff, rv), t = lane_ld<2>(xb, voff, rt);   // streamed once: nt
-      const R e = x - gl;
-      const R acc = t * q.inv_mass - grav;                  // planner.py:535-537
-      const R dev = t - hov;                                // planner.py:542
-      sp += e * e;
-      sv += v * v;
-      sa += acc * acc;
-      st += dev * dev;
-      if (k == N - 1) sterm += e * e;                       // planner.py:546-548
-      if (g != nullptr) {
-        lane_st<2>(gb, voff, rp, q.has_goal ? (R)2 * q.wp * e : (R)0);   // planner.py:567-570 (no terminal x10)
-        lane_st<2>(gb, voff, rv, (R)2 * q.wv * v);                       // planner.py:573-574
-        lane_st<2>(gb, voff, rt, (R)2 * q.wT * t);                       // planner.py:577-578 (no hover offset, no accel term)
+  for (int k0 = 0; k0 < N; k0 += kChunk) {
+    R x[kChunk], v[kChunk], t[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      if (k0 + u < N) {
+        const unsigned r = (unsigned)(3 * (k0 + u) + a);
+        x[u] = lane_ld<2>(xb, voff, r * rowb);
+        v[u] = lane_ld<2>(xb, voff, (unsigned)(N3 + r) * rowb);
+        t[u] = lane_ld<2>(xb, voff, (unsigned)(2 * N3 + r) * rowb);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      if (k0 + u < N) {
+        const unsigned r = (unsigned)(3 * (k0 + u) + a);
+        const R e = x[u] - gl;
+        const R acc = t[u] * q.inv_mass - grav;             // planner.py:535-537
+        const R dev = t[u] - hov;                           // planner.py:542
+        sp += e * e; sv += v[u] * v[u]; sa += acc * acc; st += dev * dev;
+        if (k0 + u == N - 1) sterm += e * e;                // planner.py:546-548
+        if (WANT_G) {
+          lane_st<2>(gb, voff, r * rowb, two_wp * e);                         // planner.py:567-570 (no terminal x10)
+          lane_st<2>(gb, voff, (unsigned)(N3 + r) * rowb, two_wv * v[u]);     // planner.py:573-574
+          lane_st<2>(gb, voff, (unsigned)(2 * N3 + r) * rowb, two_wT * t[u]); // planner.py:577-578 (no hover offset, no accel term)
+        }
       }
     }
   }
-  R cost = q.wv * sv + q.wa * sa + q.wT * st;
-  if (q.has_goal) cost += q.wp * sp + q.term * q.wp * sterm;
-  if (live) f[b] = cost;
+  R c = q.wv * sv + q.wa * sa + q.wT * st;
+  if (q.has_goal) c += q.wp * sp + q.term * q.wp * sterm;
+  part[a][lane] = c;
+  __syncthreads();
+  if (a == 0 && live) f[b] = part[0][lane] + part[1][lane] + part[2][lane];
 }
 
 // ------------------------------------------------------------------------------------------
 // a8: dynamics equality residuals (planner.py:426-462)
 // ------------------------------------------------------------------------------------------
 template <typename R>
-__global__ void dynamics_residual_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X,
-                                         const R* __restrict__ p0, const R* __restrict__ v0, R* __restrict__ Rout) {
-  const LaneIdx li = lane_index<R>(B);
-  if (!li.live) return;
-  const int b = li.b;
-  (void)b;
-  const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
+__global__ void __launch_bounds__(192)
+dynamics_residual_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X,
+                         const R* __restrict__ p0, const R* __restrict__ v0, R* __restrict__ Rout) {
+  // axis-split, chunked (see cost_grad_kernel): the residuals of one axis need only that axis' rows
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int b0 = blk * kWave + (int)(threadIdx.x & (kWave - 1));
+  if (b0 >= B) return;
+  const unsigned voff = (unsigned)b0 * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
   const int N = q.N, N3 = 3 * q.N;
-  for (int a = 0; a < 3; ++a) {
-    const R grav = (a == 2) ? q.grav : (R)0;
-    R pk = lane_ld<2>(lane_buf(X), voff, (unsigned)(a) * rowb);
-    R vk = lane_ld<2>(lane_buf(X), voff, (unsigned)(N3 + a) * rowb);
-    lane_st<2>(lane_buf(Rout), voff, (unsigned)(a) * rowb, (R)(pk - lane_ld<2>(lane_buf(p0), voff, (unsigned)(a) * rowb)));            // planner.py:439
-    lane_st<2>(lane_buf(Rout), voff, (unsigned)(3 + a) * rowb, (R)(vk - lane_ld<2>(lane_buf(v0), voff, (unsigned)(a) * rowb)));      // planner.py:440
-    for (int k = 0; k + 1 < N; ++k) {
-      const R tk = lane_ld<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * k + a) * rowb);
-      const R pn = lane_ld<2>(lane_buf(X), voff, (unsigned)(3 * (k + 1) + a) * rowb);
-      const R vn = lane_ld<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * (k + 1) + a) * rowb);
-      const R acc = tk / q.mass - grav;                                // planner.py:445-447
-      lane_st<2>(lane_buf(Rout), voff, (unsigned)(6 + 6 * k + a) * rowb, (R)(pn - pk - vk * q.dt - (R)0.5 * acc * (q.dt * q.dt)));   // :450-455
-      lane_st<2>(lane_buf(Rout), voff, (unsigned)(6 + 6 * k + 3 + a) * rowb, (R)(vn - vk - acc * q.dt));                             // :459
-      pk = pn; vk = vn;
+  const LaneBuf<R> xb = lane_buf(X), rb = lane_buf(Rout);
+  const R grav = (a == 2) ? q.grav : (R)0;
+  const R dt2 = q.dt * q.dt;
+  R pk = lane_ld<2>(xb, voff, (unsigned)(a) * rowb);
+  R vk = lane_ld<2>(xb, voff, (unsigned)(N3 + a) * rowb);
+  lane_st<2>(rb, voff, (unsigned)(a) * rowb, (R)(pk - lane_ld<2>(lane_buf(p0), voff, (unsigned)(a) * rowb)));        // planner.py:439
+  lane_st<2>(rb, voff, (unsigned)(3 + a) * rowb, (R)(vk - lane_ld<2>(lane_buf(v0), voff, (unsigned)(a) * rowb)));    // planner.py:440
+  for (int k0 = 0; k0 + 1 < N; k0 += kChunk) {
+    R t[kChunk], pn[kChunk], vn[kChunk];
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      if (k0 + u + 1 < N) {
+        const int k = k0 + u;
+        t[u] = lane_ld<2>(xb, voff, (unsigned)(2 * N3 + 3 * k + a) * rowb);
+        pn[u] = lane_ld<2>(xb, voff, (unsigned)(3 * (k + 1) + a) * rowb);
+        vn[u] = lane_ld<2>(xb, voff, (unsigned)(N3 + 3 * (k + 1) + a) * rowb);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kChunk; ++u) {
+      if (k0 + u + 1 < N) {
+        const int k = k0 + u;
+        const R acc = t[u] / q.mass - grav;                                                                // planner.py:445-447
+        lane_st<2>(rb, voff, (unsigned)(6 + 6 * k + a) * rowb, (R)(pn[u] - pk - vk * q.dt - (R)0.5 * acc * dt2));   // :450-455
+        lane_st<2>(rb, voff, (unsigned)(6 + 6 * k + 3 + a) * rowb, (R)(vn[u] - vk - acc * q.dt));                    // :459
+        pk = pn[u]; vk = vn[u];
+      }
     }
   }
 }
@@ -283,26 +323,44 @@ __global__ void obstacle_reduce_kernel(DevParams<R> q, int B, int ld, const R* _
 // a10: physical feasibility constraints (planner.py:472-497)
 // ------------------------------------------------------------------------------------------
 template <typename R>
-__global__ void physical_constraints_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, R* __restrict__ C) {
+__global__ void __launch_bounds__(64)
+physical_constraints_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ X, R* __restrict__ C) {
+  // every row of the result needs all three axes of a step, so one wavefront keeps whole steps; the six rows of each of
+  // kPhysChunk steps are requested before the first use
+  constexpr int kPhysChunk = 8;
   const LaneIdx li = lane_index<R>(B);
   if (!li.live) return;
-  const int b = li.b;
-  (void)b;
   const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N, N3 = 3 * q.N;
-#pragma unroll 4
-  for (int k = 0; k < N; ++k) {
-    R v2 = 0, a2 = 0, t2 = 0;
-    for (int a = 0; a < 3; ++a) {
-      const R v = lane_ld<2>(lane_buf(X), voff, (unsigned)(N3 + 3 * k + a) * rowb);
-      const R t = lane_ld<2>(lane_buf(X), voff, (unsigned)(2 * N3 + 3 * k + a) * rowb);
-      const R acc = t / q.mass - ((a == 2) ? q.grav : (R)0);
-      v2 += v * v; a2 += acc * acc; t2 += t * t;
+  const LaneBuf<R> xb = lane_buf(X), cb = lane_buf(C);
+  for (int k0 = 0; k0 < N; k0 += kPhysChunk) {
+    R v[kPhysChunk][3], t[kPhysChunk][3];
+#pragma unroll
+    for (int u = 0; u < kPhysChunk; ++u) {
+      if (k0 + u < N) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          v[u][a] = lane_ld<2>(xb, voff, (unsigned)(N3 + 3 * (k0 + u) + a) * rowb);
+          t[u][a] = lane_ld<2>(xb, voff, (unsigned)(2 * N3 + 3 * (k0 + u) + a) * rowb);
+        }
+      }
     }
-    lane_st<2>(lane_buf(C), voff, (unsigned)(k) * rowb, (R)(q.v_max2 - v2));                             // planner.py:479-481
-    lane_st<2>(lane_buf(C), voff, (unsigned)(N + k) * rowb, (R)(q.a_max2 - a2));                       // planner.py:484-489
-    lane_st<2>(lane_buf(C), voff, (unsigned)(2 * N + 2 * k) * rowb, (R)(q.t_max2 - t2));               // planner.py:494
-    lane_st<2>(lane_buf(C), voff, (unsigned)(2 * N + 2 * k + 1) * rowb, (R)(t2 - q.t_min2));           // planner.py:495
+#pragma unroll
+    for (int u = 0; u < kPhysChunk; ++u) {
+      if (k0 + u < N) {
+        const int k = k0 + u;
+        R v2 = 0, a2 = 0, t2 = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const R acc = t[u][a] / q.mass - ((a == 2) ? q.grav : (R)0);
+          v2 += v[u][a] * v[u][a]; a2 += acc * acc; t2 += t[u][a] * t[u][a];
+        }
+        lane_st<2>(cb, voff, (unsigned)(k) * rowb, (R)(q.v_max2 - v2));                             // planner.py:479-481
+        lane_st<2>(cb, voff, (unsigned)(N + k) * rowb, (R)(q.a_max2 - a2));                       // planner.py:484-489
+        lane_st<2>(cb, voff, (unsigned)(2 * N + 2 * k) * rowb, (R)(q.t_max2 - t2));               // planner.py:494
+        lane_st<2>(cb, voff, (unsigned)(2 * N + 2 * k + 1) * rowb, (R)(t2 - q.t_min2));           // planner.py:495
+      }
+    }
   }
 }
 
@@ -353,30 +411,46 @@ __device__ __forceinline__ void attitude_step(const R t[3], R inv_dt, AttitudeSt
 }
 
 template <typename R>
-__global__ void extract_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ T, R* __restrict__ acc,
-                               R* __restrict__ att, R* __restrict__ rates, R* __restrict__ thrust) {
+__global__ void __launch_bounds__(64)
+extract_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ T, R* __restrict__ acc,
+               R* __restrict__ att, R* __restrict__ rates, R* __restrict__ thrust) {
+  // write-heavy (3 rows in, 10 out per step); the thrust rows of kExtChunk steps are requested before the first use, the
+  // attitude recurrence (prev_R) runs over them in order
   const LaneIdx li = lane_index<R>(B);
   if (!li.live) return;
-  const int b = li.b;
-  (void)b;
   const unsigned voff = li.voff, rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int N = q.N;
+  const LaneBuf<R> tb = lane_buf(T);
   AttitudeState<R> prev;
   prev.valid = false;
   for (int i = 0; i < 3; ++i) prev.b1[i] = prev.b2[i] = prev.b3[i] = (R)0;
-#pragma unroll 2
-  for (int k = 0; k < N; ++k) {
-    R t[3];
-    for (int a = 0; a < 3; ++a) t[a] = lane_ld<2>(lane_buf(T), voff, (unsigned)(3 * k + a) * rowb);
-    R at[3], rt[3], mag;
-    attitude_step<R>(t, q.inv_dt, prev, at, rt, mag);
-    for (int a = 0; a < 3; ++a) {
-      const size_t r = (size_t)(3 * k + a) * ld + b;
-      if (acc != nullptr) acc[r] = t[a] / q.mass - ((a == 2) ? q.grav : (R)0);   // planner.py:589
-      if (att != nullptr) att[r] = at[a];
-      if (rates != nullptr) rates[r] = rt[a];
+  constexpr int kExtChunk = 8;                             // fully unrolled below: register indices must be compile-time
+  for (int k0 = 0; k0 < N; k0 += kExtChunk) {
+    R tt[kExtChunk][3];
+#pragma unroll
+    for (int u = 0; u < kExtChunk; ++u) {
+      if (k0 + u < N) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) tt[u][a] = lane_ld<2>(tb, voff, (unsigned)(3 * (k0 + u) + a) * rowb);
+      }
     }
-    if (thrust != nullptr) lane_st<2>(lane_buf(thrust), voff, (unsigned)(k) * rowb, (R)(mag));                      // planner.py:601
+#pragma unroll
+    for (int u = 0; u < kExtChunk; ++u) {
+      if (k0 + u < N) {
+        const int k = k0 + u;
+        R t[3] = {tt[u][0], tt[u][1], tt[u][2]};
+        R at[3], rt[3], mag;
+        attitude_step<R>(t, q.inv_dt, prev, at, rt, mag);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          const unsigned r = (unsigned)(3 * k + a) * rowb;
+          if (acc != nullptr) lane_st<2>(lane_buf(acc), voff, r, (R)(t[a] / q.mass - ((a == 2) ? q.grav : (R)0)));   // planner.py:589
+          if (att != nullptr) lane_st<2>(lane_buf(att), voff, r, at[a]);
+          if (rates != nullptr) lane_st<2>(lane_buf(rates), voff, r, rt[a]);
+        }
+        if (thrust != nullptr) lane_st<2>(lane_buf(thrust), voff, (unsigned)(k) * rowb, (R)(mag));                  // planner.py:601
+      }
+    }
   }
 }
 
@@ -1338,7 +1412,7 @@ int init_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, c
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !X0 || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
-  hipLaunchKernelGGL(init_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(init_kernel<R>, dim3(grid_for(B, kWave)), dim3(192), 0, (hipStream_t)stream,
                      make_dev_params<R>(*p), B, ld, p0, v0, goal, project, X0);
   return launch_status("se3mpc_init");
 }
@@ -1350,8 +1424,12 @@ int cost_grad_impl(const se3mpc_params* p, int B, int ld, const R* X, const R* g
   if (B == 0) return SE3MPC_OK;
   if (!X || !f || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
   if ((uint64_t)9 * p->horizon * (uint64_t)ld * sizeof(R) >= (1ull << 32)) return SE3MPC_ERR_SHAPE;   // 32-bit buffer offsets
-  hipLaunchKernelGGL(cost_grad_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
-                     make_dev_params<R>(*p), B, ld, X, goal, f, g);
+  if (g != nullptr)
+    hipLaunchKernelGGL((cost_grad_kernel<R, true>), dim3(grid_for(B, kWave)), dim3(192), 0, (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X,
+                       goal, f, g);
+  else
+    hipLaunchKernelGGL((cost_grad_kernel<R, false>), dim3(grid_for(B, kWave)), dim3(192), 0, (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X,
+                       goal, f, g);
   return launch_status("se3mpc_cost_grad");
 }
 
@@ -1362,7 +1440,7 @@ int dynamics_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, co
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!X || !p0 || !v0 || !Rout) return SE3MPC_ERR_NULL;
-  hipLaunchKernelGGL(dynamics_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
+  hipLaunchKernelGGL(dynamics_residual_kernel<R>, dim3(grid_for(B, kWave)), dim3(192), 0,
                      (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, p0, v0, Rout);
   return launch_status("se3mpc_dynamics_residual");
 }
