@@ -237,6 +237,161 @@ __device__ int bmv(const double* sy, const double* wt, int m, int col, const dou
   return 0;
 }
 
+
+// ---- register-resident small-matrix routines -------------------------------------------------
+// With the reference's options a solve stops after 1-3 iterations, i.e. the L-BFGS memory holds col = 1 or 2 pairs whenever the
+// middle matrices are used at all.  For those sizes the 2col x 2col algebra (bmv, the LEL' factorisation of formk, the two
+// triangular solves of subsm, formt's Cholesky) is a handful of flops whose cost on lane 0 was pure LDS latency: every operand a
+// dependent LDS round trip, every result a write + barrier + broadcast read (38 % of the kernel's wave-cycles sat in s_waitcnt).
+// Here every lane runs the same algebra on wave-uniform values held in REGISTERS (compile-time indices, fully unrolled): operands
+// are fetched once per section with independent broadcast reads, results are already in every lane, and only the state that must
+// survive the iteration (sy, ss, wt; pv, cv inside a Cauchy search) is written back, by lane 0.  The operation order is that of
+// the LDS routines above (LINPACK dpofa / dtrsl, bmv), so both paths produce the same bits.  col > kFastCol keeps the LDS path.
+constexpr int kFastCol = 2;
+
+template <int C>
+struct MidRegs {
+  double sy[C][C];   // S'Y, lower triangle + diagonal
+  double wt[C][C];   // Cholesky factor of theta*S'S + L D^-1 L', upper triangle
+};
+
+template <int C>
+__device__ __forceinline__ void load_mid(const double* sy, const double* wt, int m, MidRegs<C>& M) {
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+      M.sy[i][k] = (k <= i) ? sy[i * m + k] : 0.0;
+      M.wt[i][k] = (k >= i) ? wt[i * m + k] : 0.0;
+    }
+  }
+}
+
+// bmv on registers: p = M v for the 2C x 2C middle matrix
+template <int C>
+__device__ __forceinline__ int bmv_regs(const MidRegs<C>& M, const double (&v)[2 * C], double (&p)[2 * C]) {
+  p[C] = v[C];
+#pragma unroll
+  for (int i = 1; i < C; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) s += M.sy[i][k] * v[k] / M.sy[k][k];
+    p[C + i] = v[C + i] + s;
+  }
+#pragma unroll
+  for (int j = 0; j < C; ++j) if (M.wt[j][j] == 0.0) return j + 1;
+  p[C] = p[C] / M.wt[0][0];                                   // dtrsl, transposed
+#pragma unroll
+  for (int j = 1; j < C; ++j) {
+    double s = p[C + j];
+#pragma unroll
+    for (int i = 0; i < j; ++i) s -= M.wt[i][j] * p[C + i];
+    p[C + j] = s / M.wt[j][j];
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) p[i] = v[i] / sqrt(M.sy[i][i]);
+  p[C + C - 1] = p[C + C - 1] / M.wt[C - 1][C - 1];            // dtrsl, not transposed
+#pragma unroll
+  for (int j = C - 2; j >= 0; --j) {
+    const double temp = -p[C + j + 1];
+#pragma unroll
+    for (int i = 0; i <= j; ++i) p[C + i] += temp * M.wt[i][j + 1];
+    p[C + j] = p[C + j] / M.wt[j][j];
+  }
+#pragma unroll
+  for (int i = 0; i < C; ++i) p[i] = -p[i] / sqrt(M.sy[i][i]);
+#pragma unroll
+  for (int i = 0; i < C; ++i) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = i + 1; k < C; ++k) s += M.sy[k][i] * p[C + k] / M.sy[i][i];
+    p[i] += s;
+  }
+  return 0;
+}
+
+// LINPACK dpofa on the block a[OFF .. OFF+C)[OFF .. OFF+C) of an N2 x N2 register matrix (upper factor in the upper triangle)
+template <int N2, int OFF, int C>
+__device__ __forceinline__ int dpofa_regs(double (&a)[N2][N2]) {
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    double s = 0.0;
+#pragma unroll
+    for (int k = 0; k < j; ++k) {
+      double t = a[OFF + k][OFF + j];
+#pragma unroll
+      for (int i = 0; i < k; ++i) t -= a[OFF + i][OFF + k] * a[OFF + i][OFF + j];
+      t = t / a[OFF + k][OFF + k];
+      a[OFF + k][OFF + j] = t;
+      s += t * t;
+    }
+    s = a[OFF + j][OFF + j] - s;
+    if (s <= 0.0) return j + 1;
+    a[OFF + j][OFF + j] = sqrt(s);
+  }
+  return 0;
+}
+
+// dtrsl on a full N x N upper-triangular register matrix, right-hand side b
+template <int N>
+__device__ __forceinline__ int dtrsl_regs(const double (&t)[N][N], double (&b)[N], bool transposed) {
+#pragma unroll
+  for (int j = 0; j < N; ++j) if (t[j][j] == 0.0) return j + 1;
+  if (!transposed) {
+    b[N - 1] = b[N - 1] / t[N - 1][N - 1];
+#pragma unroll
+    for (int j = N - 2; j >= 0; --j) {
+      const double temp = -b[j + 1];
+#pragma unroll
+      for (int i = 0; i <= j; ++i) b[i] += temp * t[i][j + 1];
+      b[j] = b[j] / t[j][j];
+    }
+  } else {
+    b[0] = b[0] / t[0][0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) {
+      double s = b[j];
+#pragma unroll
+      for (int i = 0; i < j; ++i) s -= t[i][j] * b[i];
+      b[j] = s / t[j][j];
+    }
+  }
+  return 0;
+}
+
+// The factorisation half of formk on registers: wn = [ K11  K12 ; .  K22 ] (upper triangle) -> LEL' factor, as the LDS code:
+// dpofa(K11); K12 <- R11^-T K12 column by column; K22 += K12' K12; dpofa(K22).  0, -1 or -2.
+template <int C>
+__device__ __forceinline__ int formk_factor_regs(double (&wn)[2 * C][2 * C]) {
+  if (dpofa_regs<2 * C, 0, C>(wn)) return -1;
+#pragma unroll
+  for (int js = C; js < 2 * C; ++js) {                        // dtrsl_upper(wn, ld, col, wn + js, ld, transposed)
+    wn[0][js] = wn[0][js] / wn[0][0];
+#pragma unroll
+    for (int j = 1; j < C; ++j) {
+      double sacc = wn[j][js];
+#pragma unroll
+      for (int i = 0; i < j; ++i) sacc -= wn[i][j] * wn[i][js];
+      wn[j][js] = sacc / wn[j][j];
+    }
+  }
+#pragma unroll
+  for (int is = C; is < 2 * C; ++is) {
+#pragma unroll
+    for (int js = is; js < 2 * C; ++js) {
+      double sacc = 0.0;
+#pragma unroll
+      for (int k = 0; k < C; ++k) sacc += wn[k][is] * wn[k][js];
+      wn[is][js] += sacc;
+    }
+  }
+  if (dpofa_regs<2 * C, C, C>(wn)) return -2;
+  return 0;
+}
+
+template <int C>
+struct ColTag { static constexpr int value = C; };
+
 // ---- the solver ------------------------------------------------------------------------------
 // 2nd launch-bounds argument = wavefronts per SIMD the register allocation must leave room for: two
 // resident solves per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
@@ -460,7 +615,22 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       if (sbgnrm > 0.0 && nbreak > 0) {
         double f2 = -theta * f1;
         const double f2_org = f2;
-        if (col > 0) {
+        if (col > 0 && col <= kFastCol) {
+          auto init_fast = [&](auto tag) {
+            constexpr int C = decltype(tag)::value;
+            MidRegs<C> M;
+            load_mid<C>(sy, wt, m, M);
+            double v[2 * C], pr[2 * C];
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) v[i] = pv[i];
+            info = bmv_regs<C>(M, v, pr);
+            double dot = 0.0;
+#pragma unroll
+            for (int i = 0; i < 2 * C; ++i) dot += pr[i] * v[i];
+            f2 -= dot;
+          };
+          if (col == 1) init_fast(ColTag<1>{}); else init_fast(ColTag<2>{});
+        } else if (col > 0) {
           if (lane == 0) {
             const int inf = bmv(sy, wt, m, col, pv, vv);
             double dot = 0.0;
@@ -508,7 +678,37 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             const double dibp2 = dibp * dibp;
             f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
             f2 = f2 - theta * dibp2;
-            if (col > 0) {
+            if (col > 0 && col <= kFastCol) {
+              const int ibp = src + kWave * jsel;
+              auto step_fast = [&](auto tag) {
+                constexpr int C = decltype(tag)::value;
+                MidRegs<C> M;
+                load_mid<C>(sy, wt, m, M);
+                double pr[2 * C], cr[2 * C], wb[2 * C], vr[2 * C];
+#pragma unroll
+                for (int i = 0; i < 2 * C; ++i) { pr[i] = pv[i]; cr[i] = cv[i]; }
+#pragma unroll
+                for (int c = 0; c < C; ++c) { wb[c] = (double)wy[c * npad + ibp]; wb[C + c] = theta * (double)ws[c * npad + ibp]; }
+#pragma unroll
+                for (int i = 0; i < 2 * C; ++i) cr[i] += dt * pr[i];
+                info = bmv_regs<C>(M, wb, vr);
+                double wmc = 0.0, wmp = 0.0, wmw = 0.0;
+#pragma unroll
+                for (int i = 0; i < 2 * C; ++i) { wmc += cr[i] * vr[i]; wmp += pr[i] * vr[i]; wmw += wb[i] * vr[i]; }
+#pragma unroll
+                for (int i = 0; i < 2 * C; ++i) pr[i] -= dibp * wb[i];
+                __syncthreads();                               // every lane has read pv / cv before lane 0 overwrites them
+                if (lane == 0) {
+#pragma unroll
+                  for (int i = 0; i < 2 * C; ++i) { pv[i] = pr[i]; cv[i] = cr[i]; }
+                }
+                __syncthreads();
+                f1 += dibp * wmc;
+                f2 += 2.0 * dibp * wmp - dibp2 * wmw;
+              };
+              if (col == 1) step_fast(ColTag<1>{}); else step_fast(ColTag<2>{});
+              if (info != 0) break;
+            } else if (col > 0) {
               const int ibp = src + kWave * jsel;
               if (lane == 0) {
                 for (int i = 0; i < 2 * col; ++i) cv[i] += dt * pv[i];
@@ -554,88 +754,174 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     for (int j = 0; j < J; ++j) nfree_p += (iwhere[j] <= 0) ? 1 : 0;
     const int nfree = wave_sum_i32(nfree_p);
     if (nfree != 0 && col != 0) {
-      // ---- formk: K blocks from inner products over the free (Z) and active (A) sets
-      for (int iy = 0; iy < col; ++iy) {
-        for (int jy = 0; jy < col; ++jy) {
-          double yzzy = 0.0, saas = 0.0, sa_y = 0.0, sz_y = 0.0;
+      // wvr: the subspace solution (K^-1 W'Z r) of the fast path, in registers of every lane; the LDS path leaves it in wv[]
+      double wvr[2 * kFastCol] = {0.0, 0.0, 0.0, 0.0};
+      if (col <= kFastCol) {
+        auto subspace_fast = [&](auto tag) {
+          constexpr int C = decltype(tag)::value;
+          // ---- formk: the same inner products, accumulated into a register matrix (upper triangle of the 2C x 2C K matrix)
+          double wnr[2 * C][2 * C];
 #pragma unroll
-          for (int j = 0; j < J; ++j) {
-            const bool fr = iwhere[j] <= 0;
-            const double wyi = (double)WY(iy, j), wyj = (double)WY(jy, j), wsi = (double)WS(iy, j), wsj = (double)WS(jy, j);
-            if (fr) { yzzy += wyi * wyj; sz_y += wsi * wyj; }
-            else { saas += wsi * wsj; sa_y += wsi * wyj; }     // active set (padding rows of S, Y are zero)
-          }
-          // wn (upper triangle, row stride 2m):  [ D + Y'ZZ'Y/theta   -L_a' + R_z' ;  .   theta S'AA'S ]
-          if (jy <= iy) {
-            yzzy = wave_sum(yzzy); saas = wave_sum(saas);
-            if (lane == 0) {
-              wn[jy * 2 * m + iy] = yzzy / theta + (jy == iy ? sy[iy * m + iy] : 0.0);
-              wn[(col + jy) * 2 * m + (col + iy)] = saas * theta;
+          for (int i = 0; i < 2 * C; ++i)
+#pragma unroll
+            for (int k = 0; k < 2 * C; ++k) wnr[i][k] = 0.0;
+#pragma unroll
+          for (int iy = 0; iy < C; ++iy) {
+#pragma unroll
+            for (int jy = 0; jy < C; ++jy) {
+              double yzzy = 0.0, saas = 0.0, sa_y = 0.0, sz_y = 0.0;
+#pragma unroll
+              for (int j = 0; j < J; ++j) {
+                const bool fr = iwhere[j] <= 0;
+                const double wyi = (double)WY(iy, j), wyj = (double)WY(jy, j), wsi = (double)WS(iy, j), wsj = (double)WS(jy, j);
+                if (fr) { yzzy += wyi * wyj; sz_y += wsi * wyj; }
+                else { saas += wsi * wsj; sa_y += wsi * wyj; }
+              }
+              if (jy <= iy) {
+                yzzy = wave_sum(yzzy); saas = wave_sum(saas);
+                wnr[jy][iy] = yzzy / theta + (jy == iy ? sy[iy * m + iy] : 0.0);
+                wnr[C + jy][C + iy] = saas * theta;
+              }
+              if (jy < iy) wnr[jy][C + iy] = -wave_sum(sa_y);
+              else wnr[jy][C + iy] = wave_sum(sz_y);
             }
           }
-          if (jy < iy) {
-            sa_y = wave_sum(sa_y);
-            if (lane == 0) wn[jy * 2 * m + (col + iy)] = -sa_y;
-          } else {
-            sz_y = wave_sum(sz_y);
-            if (lane == 0) wn[jy * 2 * m + (col + iy)] = sz_y;
+          int inf = formk_factor_regs<C>(wnr);
+          // ---- cmprlb, scalar part: mc = M c
+          MidRegs<C> M;
+          load_mid<C>(sy, wt, m, M);
+          double cr[2 * C], mc[2 * C];
+#pragma unroll
+          for (int i = 0; i < 2 * C; ++i) cr[i] = cv[i];
+          if (inf == 0 && bmv_regs<C>(M, cr, mc)) inf = -8;
+          info = inf;
+          if (info != 0) return;
+          // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
+#pragma unroll
+          for (int j = 0; j < J; ++j) d[j] = (iwhere[j] <= 0) ? (-theta * (z[j] - x[j]) - g[j]) : 0.0;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            const double a1 = mc[c], a2 = theta * mc[C + c];
+#pragma unroll
+            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * a1 + (double)WS(c, j) * a2;
           }
-        }
-      }
-      __syncthreads();
-      if (lane == 0) {
-        const int ld = 2 * m;
-        int inf = dpofa(wn, ld, col);
-        if (inf) inf = -1;
-        else {
-          for (int js = col; js < 2 * col; ++js) dtrsl_upper(wn, ld, col, wn + js, ld, true);
-          for (int is = col; is < 2 * col; ++is)
-            for (int js = is; js < 2 * col; ++js) {
-              double s = 0.0;
-              for (int k = 0; k < col; ++k) s += wn[k * ld + is] * wn[k * ld + js];
-              wn[is * ld + js] += s;
+          // ---- subsm: wv = W'Z d ; wv = K^-1 wv
+          double wr[2 * C];
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+            wr[c] = wave_sum(a1); wr[C + c] = theta * wave_sum(a2);
+          }
+          int inf2 = dtrsl_regs<2 * C>(wnr, wr, true);
+          if (!inf2) {
+#pragma unroll
+            for (int i = 0; i < C; ++i) wr[i] = -wr[i];
+            inf2 = dtrsl_regs<2 * C>(wnr, wr, false);
+          }
+          info = inf2;
+#pragma unroll
+          for (int i = 0; i < C; ++i) { wvr[i] = wr[i]; wvr[kFastCol + i] = wr[C + i]; }
+        };
+        if (col == 1) subspace_fast(ColTag<1>{}); else subspace_fast(ColTag<2>{});
+      } else {
+        // ---- formk: K blocks from inner products over the free (Z) and active (A) sets
+        for (int iy = 0; iy < col; ++iy) {
+          for (int jy = 0; jy < col; ++jy) {
+            double yzzy = 0.0, saas = 0.0, sa_y = 0.0, sz_y = 0.0;
+  #pragma unroll
+            for (int j = 0; j < J; ++j) {
+              const bool fr = iwhere[j] <= 0;
+              const double wyi = (double)WY(iy, j), wyj = (double)WY(jy, j), wsi = (double)WS(iy, j), wsj = (double)WS(jy, j);
+              if (fr) { yzzy += wyi * wyj; sz_y += wsi * wyj; }
+              else { saas += wsi * wsj; sa_y += wsi * wyj; }     // active set (padding rows of S, Y are zero)
             }
-          if (dpofa(wn + col * ld + col, ld, col)) inf = -2;
-        }
-        // ---- cmprlb, scalar part: mc = M c
-        if (inf == 0 && bmv(sy, wt, m, col, cv, vv)) inf = -8;
-        sc[0] = (double)inf;
-      }
-      __syncthreads();
-      info = (int)sc[0];
-      if (info == 0) {
-        // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
-#pragma unroll
-        for (int j = 0; j < J; ++j) d[j] = (iwhere[j] <= 0) ? (-theta * (z[j] - x[j]) - g[j]) : 0.0;
-        for (int c = 0; c < col; ++c) {
-          const double a1 = vv[c], a2 = theta * vv[col + c];
-#pragma unroll
-          for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * a1 + (double)WS(c, j) * a2;
-        }
-        // ---- subsm: wv = W'Z d ; wv = K^-1 wv ; d = (d + Z'W wv-ish)/theta
-        for (int c = 0; c < col; ++c) {
-          double a1 = 0.0, a2 = 0.0;
-#pragma unroll
-          for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
-          a1 = wave_sum(a1); a2 = wave_sum(a2);
-          if (lane == 0) { wv[c] = a1; wv[col + c] = theta * a2; }
+            // wn (upper triangle, row stride 2m):  [ D + Y'ZZ'Y/theta   -L_a' + R_z' ;  .   theta S'AA'S ]
+            if (jy <= iy) {
+              yzzy = wave_sum(yzzy); saas = wave_sum(saas);
+              if (lane == 0) {
+                wn[jy * 2 * m + iy] = yzzy / theta + (jy == iy ? sy[iy * m + iy] : 0.0);
+                wn[(col + jy) * 2 * m + (col + iy)] = saas * theta;
+              }
+            }
+            if (jy < iy) {
+              sa_y = wave_sum(sa_y);
+              if (lane == 0) wn[jy * 2 * m + (col + iy)] = -sa_y;
+            } else {
+              sz_y = wave_sum(sz_y);
+              if (lane == 0) wn[jy * 2 * m + (col + iy)] = sz_y;
+            }
+          }
         }
         __syncthreads();
         if (lane == 0) {
-          int inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, true);
-          if (!inf) {
-            for (int i = 0; i < col; ++i) wv[i] = -wv[i];
-            inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, false);
+          const int ld = 2 * m;
+          int inf = dpofa(wn, ld, col);
+          if (inf) inf = -1;
+          else {
+            for (int js = col; js < 2 * col; ++js) dtrsl_upper(wn, ld, col, wn + js, ld, true);
+            for (int is = col; is < 2 * col; ++is)
+              for (int js = is; js < 2 * col; ++js) {
+                double s = 0.0;
+                for (int k = 0; k < col; ++k) s += wn[k * ld + is] * wn[k * ld + js];
+                wn[is * ld + js] += s;
+              }
+            if (dpofa(wn + col * ld + col, ld, col)) inf = -2;
           }
+          // ---- cmprlb, scalar part: mc = M c
+          if (inf == 0 && bmv(sy, wt, m, col, cv, vv)) inf = -8;
           sc[0] = (double)inf;
         }
         __syncthreads();
         info = (int)sc[0];
         if (info == 0) {
+          // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
+  #pragma unroll
+          for (int j = 0; j < J; ++j) d[j] = (iwhere[j] <= 0) ? (-theta * (z[j] - x[j]) - g[j]) : 0.0;
           for (int c = 0; c < col; ++c) {
-            const double b1 = wv[c] / theta, b2 = wv[col + c];
+            const double a1 = vv[c], a2 = theta * vv[col + c];
+  #pragma unroll
+            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * a1 + (double)WS(c, j) * a2;
+          }
+          // ---- subsm: wv = W'Z d ; wv = K^-1 wv ; d = (d + Z'W wv-ish)/theta
+          for (int c = 0; c < col; ++c) {
+            double a1 = 0.0, a2 = 0.0;
+  #pragma unroll
+            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+            a1 = wave_sum(a1); a2 = wave_sum(a2);
+            if (lane == 0) { wv[c] = a1; wv[col + c] = theta * a2; }
+          }
+          __syncthreads();
+          if (lane == 0) {
+            int inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, true);
+            if (!inf) {
+              for (int i = 0; i < col; ++i) wv[i] = -wv[i];
+              inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, false);
+            }
+            sc[0] = (double)inf;
+          }
+          __syncthreads();
+          info = (int)sc[0];
+        }
+      }   // col > kFastCol: LDS path
+      {
+        if (info == 0) {
+          if (col <= kFastCol) {
 #pragma unroll
-            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * b1 + (double)WS(c, j) * b2;
+            for (int c = 0; c < kFastCol; ++c) {
+              if (c < col) {
+                const double b1 = wvr[c] / theta, b2 = wvr[kFastCol + c];
+#pragma unroll
+                for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * b1 + (double)WS(c, j) * b2;
+              }
+            }
+          } else {
+            for (int c = 0; c < col; ++c) {
+              const double b1 = wv[c] / theta, b2 = wv[col + c];
+#pragma unroll
+              for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * b1 + (double)WS(c, j) * b2;
+            }
           }
           const double rth = 1.0 / theta;
           // projected Newton point; xo/go are free here (the line search re-saves them): xo keeps xcp
@@ -796,30 +1082,80 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
     for (int j = 0; j < J; ++j) { WS(col - 1, j) = (IO)d[j]; WY(col - 1, j) = (IO)go[j]; }
     theta = rr / dr;
-    for (int c = 0; c + 1 < col; ++c) {
-      double a1 = 0.0, a2 = 0.0;
+    bool formt_failed;
+    if (col <= kFastCol) {
+      // matupd's new row / column and formt on registers: every lane forms theta*S'S + L D^-1 L' and its Cholesky factor from
+      // wave-uniform values; lane 0 writes the state (sy, ss, wt) back for the next iteration
+      auto update_fast = [&](auto tag) {
+        constexpr int C = decltype(tag)::value;
+        double syr[C][C], ssr[C][C], wtr[C][C];
 #pragma unroll
-      for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
-      a1 = wave_sum(a1); a2 = wave_sum(a2);
-      if (lane == 0) { sy[(col - 1) * m + c] = a1; ss[c * m + (col - 1)] = a2; }
-    }
-    if (lane == 0) {
-      ss[(col - 1) * m + (col - 1)] = (stp == 1.0) ? dtd : stp * stp * dtd;
-      sy[(col - 1) * m + (col - 1)] = dr;
-      // formt: T = theta*S'S + L D^-1 L', Cholesky factor in wt
-      for (int jj = 0; jj < col; ++jj) wt[jj] = theta * ss[jj];
-      for (int i = 1; i < col; ++i)
-        for (int jj = i; jj < col; ++jj) {
-          const int k1 = i < jj ? i : jj;
-          double dd = 0.0;
-          for (int k = 0; k < k1; ++k) dd += sy[i * m + k] * sy[jj * m + k] / sy[k * m + k];
-          wt[i * m + jj] = dd + theta * ss[i * m + jj];
+        for (int i = 0; i < C; ++i)
+#pragma unroll
+          for (int k = 0; k < C; ++k) { syr[i][k] = (k <= i && i < C - 1) ? sy[i * m + k] : 0.0; ssr[i][k] = (k >= i && k < C - 1) ? ss[i * m + k] : 0.0; wtr[i][k] = 0.0; }
+#pragma unroll
+        for (int c = 0; c + 1 < C; ++c) {
+          double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+          for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
+          syr[C - 1][c] = wave_sum(a1); ssr[c][C - 1] = wave_sum(a2);
         }
-      sc[0] = (double)dpofa(wt, m, col);
+        ssr[C - 1][C - 1] = (stp == 1.0) ? dtd : stp * stp * dtd;
+        syr[C - 1][C - 1] = dr;
+        // formt: T = theta*S'S + L D^-1 L', Cholesky factor in wt
+#pragma unroll
+        for (int jj = 0; jj < C; ++jj) wtr[0][jj] = theta * ssr[0][jj];
+#pragma unroll
+        for (int i = 1; i < C; ++i)
+#pragma unroll
+          for (int jj = i; jj < C; ++jj) {
+            const int k1 = i < jj ? i : jj;
+            double dd = 0.0;
+#pragma unroll
+            for (int k = 0; k < C; ++k) if (k < k1) dd += syr[i][k] * syr[jj][k] / syr[k][k];
+            wtr[i][jj] = dd + theta * ssr[i][jj];
+          }
+        formt_failed = dpofa_regs<C, 0, C>(wtr) != 0;
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+          for (int c = 0; c < C; ++c) { sy[(C - 1) * m + c] = syr[C - 1][c]; ss[c * m + (C - 1)] = ssr[c][C - 1]; }
+#pragma unroll
+          for (int i = 0; i < C; ++i)
+#pragma unroll
+            for (int jj = 0; jj < C; ++jj) if (jj >= i) wt[i * m + jj] = wtr[i][jj];
+        }
+        __syncthreads();
+      };
+      if (col == 1) update_fast(ColTag<1>{}); else update_fast(ColTag<2>{});
+    } else {
+      for (int c = 0; c + 1 < col; ++c) {
+        double a1 = 0.0, a2 = 0.0;
+  #pragma unroll
+        for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
+        a1 = wave_sum(a1); a2 = wave_sum(a2);
+        if (lane == 0) { sy[(col - 1) * m + c] = a1; ss[c * m + (col - 1)] = a2; }
+      }
+      if (lane == 0) {
+        ss[(col - 1) * m + (col - 1)] = (stp == 1.0) ? dtd : stp * stp * dtd;
+        sy[(col - 1) * m + (col - 1)] = dr;
+        // formt: T = theta*S'S + L D^-1 L', Cholesky factor in wt
+        for (int jj = 0; jj < col; ++jj) wt[jj] = theta * ss[jj];
+        for (int i = 1; i < col; ++i)
+          for (int jj = i; jj < col; ++jj) {
+            const int k1 = i < jj ? i : jj;
+            double dd = 0.0;
+            for (int k = 0; k < k1; ++k) dd += sy[i * m + k] * sy[jj * m + k] / sy[k * m + k];
+            wt[i * m + jj] = dd + theta * ss[i * m + jj];
+          }
+        sc[0] = (double)dpofa(wt, m, col);
+      }
+      __syncthreads();
+      formt_failed = sc[0] != 0.0;
+      __syncthreads();
     }
-    __syncthreads();
-    if (sc[0] != 0.0) { col = 0; theta = 1.0; iupdat = 0; }
-    __syncthreads();
+    if (formt_failed) { col = 0; theta = 1.0; iupdat = 0; }
+
   }
 
   // ===================================================================== results
