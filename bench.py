@@ -70,6 +70,8 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE config-2 / config-3 legs")
     ap.add_argument("--no-iterated", action="store_true", help="skip the on-device K-iteration leg")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop Monte-Carlo leg")
+    ap.add_argument("--iterated-ks", default="0,1,4,16,64", help="iteration counts of the on-device iteration leg (profiling: one value)")
+    ap.add_argument("--no-primary", action="store_true", help="profiling only: skip the rollout legs (no JSON line is printed)")
     return ap.parse_args()
 
 
@@ -353,7 +355,7 @@ def main():
 
     results = {}
     for mode, per_l in (("primary", S), ("single_launch", 1)):
-        if mode == "single_launch" and (S == 1 or a.no_single):
+        if a.no_primary or (mode == "single_launch" and (S == 1 or a.no_single)):
             continue
         # calibration: device time of one pass (also the untimed warm-up: W steps rounded up to whole launches)
         lpp = max(1, math.ceil(K / per_l))
@@ -388,17 +390,19 @@ def main():
                              steps_timed=plan["repeats"] * plan["steps_per_pass"], plan=plan, device_ms=dev_ms,
                              keys_valid=bool(np.all((kh & np.uint64(0xFFFFFFFF)) < np.uint64(world * B))))
         del graph
-    del state["wave_keys"], state["keys"]
+    state.pop("wave_keys", None); state.pop("keys", None)
 
     solve_stats = None if a.no_solve else solve_leg(torch, ops, dev, B, N, rank, world)
     voxel_stats = None if (a.no_obstacle_source or rank != 0) else obstacle_source_leg(torch, ops, dev)
     del p0, v0, goal, T, cost, grad
     torch.cuda.empty_cache()
     config_stats = None if (a.no_configs or rank != 0) else config_legs(torch, ops, dev, a.min_ms)
-    iter_stats = None if (a.no_iterated or rank != 0) else iterated_leg(torch, ops, dev, B, N, a.min_ms)
+    iter_stats = None if (a.no_iterated or rank != 0) else iterated_leg(torch, ops, dev, B, N, a.min_ms, tuple(int(k) for k in a.iterated_ks.split(",")))
     loop_stats = None if (a.no_closed_loop or rank != 0) else closed_loop_leg(torch, ops, dev)
 
-    if rank == 0:
+    if rank == 0 and a.no_primary:
+        print(json.dumps({"profiling_only": True, "iterated": iter_stats, "configs": config_stats, "closed_loop": loop_stats, "solve": solve_stats}), flush=True)
+    elif rank == 0:
         r = results["primary"]
         per_launch_rollouts = B * S
         achieved = bytes_per_rollout * per_launch_rollouts / (r["launch_ms"] * 1e-3) / 1e9
@@ -624,7 +628,7 @@ def config_legs(torch, ops, dev, min_ms):
     return out
 
 
-def iterated_leg(torch, ops, dev, B, N, min_ms):
+def iterated_leg(torch, ops, dev, B, N, min_ms, ks=(0, 1, 4, 16, 64)):
     """The on-device iteration loop (se3mpc_rollout_iterate_*): K projected-gradient iterations of the shooting form + one last
     evaluation in ONE launch, thrust sequences resident in registers, against the same K + 1 evaluations issued as one launch each
     (`single_launch` leg).  Same batch (8192 x horizon 30), ring of distinct batches, hipGraph replay, HIP-event time."""
@@ -638,7 +642,7 @@ def iterated_leg(torch, ops, dev, B, N, min_ms):
     out = {"what": f"horizon={N}, batch={B}: K iterations of T <- clip(T - {step} dcost/dT) + a final evaluation per launch; "
                    "K + 1 rollouts per trajectory per launch, HBM traffic of one", "per_K": []}
     base_us = None
-    for K in (0, 1, 4, 16, 64):
+    for K in ks:
         nl = min(ring, 256)
         body = lambda: [ops.rollout_iterate(prm, p0[i], v0[i], goal[i], T[i], K, step, out=(Tout[i], cost[i], grad[i])) for i in range(nl)]
         body(); torch.cuda.synchronize()
@@ -647,10 +651,10 @@ def iterated_leg(torch, ops, dev, B, N, min_ms):
         reps = max(2, math.ceil(min_ms / max(ms1, 1e-6)))
         us = device_ms(torch, graph.replay, reps) / nl * 1e3
         del graph
-        if K == 0:
-            base_us = us
+        if K == 0 or base_us is None:
+            base_us = us if K == 0 else None
         hbm = 4 * (9 + 3 * N) + 4 * (1 + 6 * N)                 # per trajectory: read p0, v0, goal, T; write T, gradient, cost
-        out["per_K"].append({"K": K, "launch_us": us, "us_per_iteration": None if K == 0 else (us - base_us) / K,
+        out["per_K"].append({"K": K, "launch_us": us, "us_per_iteration": None if (K == 0 or base_us is None) else (us - base_us) / K,
                              "rollouts_per_s": B * (K + 1) / (us * 1e-6), "hbm_bytes_per_launch": hbm * B,
                              "hbm_GB_per_s": hbm * B / (us * 1e-6) / 1e9,
                              "rollout_equivalent_GB_per_s": 4 * (6 * N + 10) * B * (K + 1) / (us * 1e-6) / 1e9})

@@ -71,4 +71,29 @@ for tag, rollouts, gy in (("fused", 64 * B, 64), ("single", B, None), ("b4m", 41
                             kernel_ns_under_pmc=durations(rows_of(f"pmc_FETCH_SIZE_{tag}", "rollout_kernel"), gy),
                             fetch_bytes_raw=None if fe is None else fe["mean"] * 1024,
                             write_bytes_raw=None if wr is None else wr["mean"] * 1024)
+# ---- the on-device iteration kernel: duration per launch at K = 0 / 16 / 64 and its HBM traffic at K = 16
+it = {}
+for K in (0, 16, 64):
+    it[f"K{K}"] = durations(rows_of(f"iter_{K}", "rollout_iterate_kernel"))
+if it.get("K0") and it.get("K16") and it.get("K64"):
+    it["us_per_iteration_K16"] = (it["K16"]["avg_ns"] - it["K0"]["avg_ns"]) / 16 / 1e3
+    it["us_per_iteration_K64"] = (it["K64"]["avg_ns"] - it["K0"]["avg_ns"]) / 64 / 1e3
+fe = counter("pmc_FETCH_SIZE_iter16", "rollout_iterate_kernel", "FETCH_SIZE")
+wr = counter("pmc_WRITE_SIZE_iter16", "rollout_iterate_kernel", "WRITE_SIZE")
+it["pmc_K16"] = dict(trajectories_per_launch=B, iterations=16, rollouts_per_launch=17 * B,
+                     hbm_algorithmic_read_bytes=4 * (3 * N + 9) * B, hbm_algorithmic_write_bytes=4 * (6 * N + 1) * B,
+                     FETCH_SIZE_KB=fe, WRITE_SIZE_KB=wr,
+                     fetch_bytes_x2=None if fe is None else fe["mean"] * 1024 * 2, write_bytes=None if wr is None else wr["mean"] * 1024)
+if fe is not None and wr is not None:
+    it["pmc_K16"]["traffic_bytes_per_iteration"] = (fe["mean"] * 2048 + wr["mean"] * 1024) / 17
+    it["pmc_K16"]["stand_alone_launch_bytes_per_iteration"] = 4 * (6 * N + 10) * B
+out["rollout_iterate"] = it
+# ---- config legs and the closed loop
+cf = {}
+for name, needle, gy in (("cfg2_single_1024", "rollout_kernel", 1), ("cfg2_batched_64x1024", "rollout_kernel", 64),
+                         ("cfg3_single_8192", "rollout_obstacles_kernel", 1), ("cfg3_batched_64x8192", "rollout_obstacles_kernel", 64)):
+    cf[name] = durations(rows_of("configs", needle), gy)
+out["configs"] = cf
+out["closed_loop"] = {"closed_loop_kernel_4096x15": durations(rows_of("loop", "closed_loop_kernel")),
+                      "solve_kernel_4096_h6": durations([r for r in rows_of("loop", "solve_kernel") if int(r["Grid_Size_X"]) == 64 * 4096][0::2])}
 print(json.dumps(out, indent=1))
