@@ -669,7 +669,8 @@ def closed_loop_leg(torch, ops, dev):
     receding-horizon Monte-Carlo entirely on the device: per cycle ONE batched solve launch (every run re-plans from its own state)
     and ONE closed-loop launch (15 x plan sample -> geometric controller -> simulator at 100 Hz, plans read in place from the solver's
     outputs).  4096 runs, float32; wall time with one synchronise at the end."""
-    from dart_planner_amd.capi import ControllerParams, Params, SimulatorParams
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd.control.closed_loop import ClosedLoopMonteCarlo
     S, cycles, substeps, sim_dt = 4096, 33, 15, 0.01
     prm = Params.reference_defaults()
     N = prm.horizon
@@ -681,20 +682,10 @@ def closed_loop_leg(torch, ops, dev):
         v0 = 0.3 * torch.randn(S, 3, dtype=dtype, device=dev, generator=g)
         goal = torch.tensor([8.0, 0.0, 5.0], dtype=dtype, device=dev).repeat(S, 1).contiguous()
         wind = torch.randn(S, 3, dtype=dtype, device=dev, generator=g).contiguous()
-        k = torch.arange(N, dtype=torch.float64, device=dev)
-        stamps = [(c * substeps * sim_dt) + k * prm.dt for c in range(cycles)]
+        mc = ClosedLoopMonteCarlo(ops, prm, cp, sp)
 
         def run():
-            pos, vel = p0.clone(), v0.clone()
-            att, om = torch.zeros_like(p0), torch.zeros_like(p0)
-            time_ = torch.zeros(S, dtype=torch.float64, device=dev)
-            st = ops.controller_state(cp, S)
-            for c in range(cycles):
-                sol = ops.solve(prm, pos, vel, goal)
-                X = sol["x"]
-                ops.closed_loop(cp, sp, st, time_, pos, vel, att, om, stamps[c], X, X[:, 3 * N:], sol["accelerations"], nsteps=substeps,
-                                sim_dt=sim_dt, strides=(9 * N, 9 * N, 3 * N), wind=wind, stop_at_plan_end=False)
-            return pos
+            return mc.run(p0, v0, goal, cycles, substeps, sim_dt, wind=wind)["pos"]
         run(); torch.cuda.synchronize()
         ts = []
         for _ in range(5):

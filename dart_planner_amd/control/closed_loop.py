@@ -1,0 +1,46 @@
+"""Batched closed loop on the device: planner -> (plan sample -> geometric controller -> simulator) for many drones at once.
+
+What the reference's closed-loop tests do one drone and one Python call at a time
+(tests/test_planner_controller_contract.py:115-162, :255-316; tests/test_monte_carlo_sim.py:24-72) runs here as two launches
+per planning cycle for B drones: ``se3mpc_solve_*`` (every drone re-plans from its own state) and ``se3mpc_closed_loop_*``
+(``substeps`` control + simulator steps against the fresh plan, which is read in place from the solver's outputs).  No host
+arithmetic, no copies between the two; the only host work per cycle is the N plan stamps (planner.py:661: start + arange(N)*dt).
+"""
+from typing import Optional
+
+from ..capi import ControllerParams, Params, SimulatorParams
+
+
+class ClosedLoopMonteCarlo:
+    """Receding-horizon Monte-Carlo over B drones (BASELINE.json config 5's named test shape).
+
+    ops: dart_planner_amd.ops.Ops;  params: se3mpc_params of the planner (horizon N, dt);  controller / simulator: the
+    C-ABI parameter structs (defaults: the reference's "sitl_optimized" controller and DroneSimulator())."""
+
+    def __init__(self, ops, params: Params, controller: Optional[ControllerParams] = None, simulator: Optional[SimulatorParams] = None):
+        self.ops, self.params = ops, params
+        self.controller = controller if controller is not None else ops.lib.controller_default_params()
+        self.simulator = simulator if simulator is not None else ops.lib.simulator_default_params()
+
+    def run(self, p0, v0, goal, cycles: int, substeps: int, sim_dt: float, wind=None, log: bool = False):
+        """p0, v0, goal: (B, 3) device tensors (float32 or float64: the precision of the whole loop); wind: None, (3,) or (B, 3) newtons.
+        -> dict(pos, vel, att, omega (B, 3), time (B,), controller_state (B, 12), logs = [(solve outputs, closed-loop outputs)] if log)."""
+        import torch
+        ops, prm = self.ops, self.params
+        dev = ops.be.device
+        B, N = p0.shape[0], prm.horizon
+        pos, vel = p0.clone(), v0.clone()
+        att, om = torch.zeros_like(p0), torch.zeros_like(p0)
+        time = torch.zeros(B, dtype=torch.float64, device=dev)
+        st = ops.controller_state(self.controller, B)
+        k = torch.arange(N, dtype=torch.float64, device=dev)
+        logs = []
+        for c in range(cycles):
+            sol = ops.solve(prm, pos, vel, goal)
+            stamps = (c * substeps * sim_dt) + k * prm.dt
+            X = sol["x"]
+            out = ops.closed_loop(self.controller, self.simulator, st, time, pos, vel, att, om, stamps, X, X[:, 3 * N:], sol["accelerations"],
+                                  nsteps=substeps, sim_dt=sim_dt, strides=(9 * N, 9 * N, 3 * N), wind=wind, stop_at_plan_end=False, log=log)
+            if log:
+                logs.append((sol, out))
+        return dict(pos=pos, vel=vel, att=att, omega=om, time=time, controller_state=st, logs=logs)

@@ -97,27 +97,11 @@ def test_plan_sampler_matches_reference(gpu_ops, golden_controller):
 
 
 def monte_carlo(ops, prm, cp, sp, p0, v0, goal, cycles, substeps, sim_dt, wind, dtype, log=False):
-    """The receding-horizon Monte-Carlo on the device: per cycle ONE se3mpc_solve_* launch (every drone re-plans from its own
-    state) and ONE se3mpc_closed_loop_* launch (`substeps` control + simulator steps against the fresh plan, read in place from
-    the solver's outputs).  No host arithmetic, no copies between the two."""
-    import torch
-    dev = ops.be.device
-    S, N = p0.shape[0], prm.horizon
-    pos, vel = p0.clone(), v0.clone()
-    att, om = torch.zeros(S, 3, dtype=dtype, device=dev), torch.zeros(S, 3, dtype=dtype, device=dev)
-    time = torch.zeros(S, dtype=torch.float64, device=dev)
-    st = ops.controller_state(cp, S)
-    k = torch.arange(N, dtype=torch.float64, device=dev)
-    logs = []
-    for c in range(cycles):
-        sol = ops.solve(prm, pos, vel, goal)
-        ts = (c * substeps * sim_dt) + k * prm.dt                      # planner.py:661: start_time + arange(N) * dt
-        X = sol["x"]
-        out = ops.closed_loop(cp, sp, st, time, pos, vel, att, om, ts, X, X[:, 3 * N:], sol["accelerations"], nsteps=substeps, sim_dt=sim_dt,
-                              strides=(9 * N, 9 * N, 3 * N), wind=wind, stop_at_plan_end=False, log=log)
-        if log:
-            logs.append((sol, out))
-    return pos, vel, att, om, time, st, logs
+    """The product's receding-horizon Monte-Carlo (dart_planner_amd/control/closed_loop.py): per cycle ONE se3mpc_solve_* launch and ONE
+    se3mpc_closed_loop_* launch, plans read in place from the solver's outputs."""
+    from dart_planner_amd.control.closed_loop import ClosedLoopMonteCarlo
+    r = ClosedLoopMonteCarlo(ops, prm, cp, sp).run(p0, v0, goal, cycles, substeps, sim_dt, wind=wind, log=log)
+    return r["pos"], r["vel"], r["att"], r["omega"], r["time"], r["controller_state"], r["logs"]
 
 
 def test_monte_carlo_closed_loop_on_device(gpu_ops):
