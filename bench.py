@@ -145,7 +145,26 @@ def cpu_baseline(B, N, seconds):
         t2 = time.perf_counter()
         orc.plan_reference_shaped(np.array([0.0, 0.0, 1.0]), np.zeros(3), gi, cfg)
         ts.append((time.perf_counter() - t2) * 1e3)
+    # the closed-loop Monte-Carlo of the `closed_loop` leg, reference-shaped on one core: per run and planning cycle one SciPy solve and 15
+    # NumPy controller + simulator steps (oracle/controller_oracle.py), a bounded sample of 8 runs x 33 cycles
+    from oracle import controller_oracle as co
+    ccfg, csim, pcfg = co.ControllerConfig(), co.SimulatorConfig(), orc.OracleConfig()
+    t3 = time.perf_counter()
+    runs = 8
+    for r_ in range(runs):
+        pos, vel = np.array([[0.0, 0.0, 2.0]]) + 0.2 * rng.normal(size=(1, 3)), 0.3 * rng.normal(size=(1, 3))
+        att, om, tt = np.zeros((1, 3)), np.zeros((1, 3)), np.zeros(1)
+        cst = co.ControllerState(1, ccfg)
+        for c_ in range(33):
+            x, _ = orc.solve(pos[0], vel[0], np.array([8.0, 0.0, 5.0]), pcfg)
+            ex = orc.extract_solution(x, pcfg)
+            fin, _ = co.closed_loop(ccfg, csim, cst, pos, vel, att, om, tt, c_ * 0.15 + np.arange(6) / 400.0, x[:18].reshape(6, 3), x[18:36].reshape(6, 3),
+                                    ex["accelerations"], 15, 0.01, wind=[0.5, 0.0, 0.0], stop_at_plan_end=False, log=False)
+            pos, vel, att, om, tt = fin["pos"], fin["vel"], fin["att"], fin["omega"], fin["t"]
+    loop_s = (time.perf_counter() - t3) / runs
     return dict(value=total, unit="rollouts/s", cores=cores, kind="port",
+                closed_loop_reference_shaped=dict(what="one closed-loop run = 33 x (SciPy solve + 15 NumPy controller + simulator steps), one core",
+                                                  runs=runs, seconds_per_run=loop_s, runs_per_s=1.0 / loop_s),
                 sample=f"{cores} worker processes x {seconds:.0f} s of the oracle's batched NumPy rollout+cost+grad (float64), "
                        f"{Bs} trajectories per pass, horizon {N} ({sum(n for n, _ in res)} passes in all)",
                 single_core_value=single[0] * Bs / single[1], reference_shaped_evals_per_s=m / el1,

@@ -187,3 +187,54 @@ def test_closed_loop_random_batch_vs_oracle(emu_ops, dt):
     cc.check_closed_loop_vs_oracle(harness(emu_ops, dt), B=70, N=12, nsteps=24, seed=1)
     if dt == np.float64:
         cc.check_closed_loop_vs_oracle(harness(emu_ops, dt), B=5, N=12, nsteps=24, seed=2, per_drone_plans=False)
+
+
+def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
+    """se3mpc_rollout_iterate / projected_step / control / control_plan / simulator_step / closed_loop / controller_reset:
+    B == 0 is a no-op, NULL and shape errors come back as status codes, bad parameter structs are refused."""
+    lib, be = emu_ops.lib, emu_ops.be
+    prm = capi.Params.reference_defaults(horizon=6)
+    st = lambda *args, **kw: lib.call_status(*args, **kw)
+    a = np.zeros((3, 4), dtype=np.float32); T = np.zeros((18, 4), dtype=np.float32); f = np.zeros(4, dtype=np.float32)
+    it = lambda B, ld, nb, iters, step, T_in, T_out, cost: st("rollout_iterate", "f32", B, ld, nb, iters, step, be.ptr(a), be.ptr(a), be.ptr(a), T_in, T_out, 0,
+                                                              cost, 0, 0, 0, 0, params=prm)
+    assert it(0, 4, 1, 3, 0.5, 0, 0, 0) == 0                                   # B == 0
+    assert it(4, 4, 1, 3, 0.5, be.ptr(T), be.ptr(T), be.ptr(f)) == 0          # in place
+    assert it(4, 4, 1, 3, 0.5, 0, be.ptr(T), be.ptr(f)) == -1                 # NULL T_in
+    assert it(4, 4, 1, -1, 0.5, be.ptr(T), be.ptr(T), be.ptr(f)) == -3        # iters < 0
+    assert it(4, 4, 0, 3, 0.5, be.ptr(T), be.ptr(T), be.ptr(f)) == -3         # nbatch < 1
+    assert it(5, 4, 1, 3, 0.5, be.ptr(T), be.ptr(T), be.ptr(f)) == -3         # ld < B
+    assert it(4, 4, 1, 3, float("nan"), be.ptr(T), be.ptr(T), be.ptr(f)) == -4
+    assert st("projected_step", "f32", 4, 4, 0.5, be.ptr(T), 0, be.ptr(T), 0, params=prm) == -1
+    assert st("projected_step", "f32", 0, 4, 0.5, 0, 0, 0, 0, params=prm) == 0
+    cp, sp = lib.controller_default_params(), lib.simulator_default_params()
+    ls = lambda *args: lib.loop_status(*args)
+    z3 = np.zeros((2, 3)); t = np.zeros(2); state = emu_ops.controller_state(cp, 2); th = np.zeros(2); tq = np.zeros((2, 3))
+    p = be.ptr
+    ctl = lambda cpx, B, time, pos, stt: ls("control", "f64", cpx, B, time, pos, p(z3), p(z3), p(z3), p(z3), p(z3), 0, 0, 0, stt, p(th), p(tq), 0, 0, 0, 0)
+    assert ctl(cp, 0, 0, 0, 0) == 0
+    assert ctl(cp, 2, p(t), p(z3), p(state)) == 0
+    assert ctl(cp, 2, 0, p(z3), p(state)) == -1 and ctl(cp, 2, p(t), p(z3), 0) == -1 and ctl(cp, -1, p(t), p(z3), p(state)) == -3
+    bad = lib.controller_default_params(); bad.mass = 0.0
+    assert ctl(bad, 2, p(t), p(z3), p(state)) == -4
+    bad = lib.controller_default_params(); bad.kp_pos[1] = float("inf")
+    assert ctl(bad, 2, p(t), p(z3), p(state)) == -4
+    bad = lib.controller_default_params(); bad.yaw_fallback_method = 7
+    assert ctl(bad, 2, p(t), p(z3), p(state)) == -4
+    assert lib._dll.se3mpc_controller_reset(None, 2, p(state), 0) == -1
+    ts = np.array([0.0, 1.0]); P = np.zeros((2, 3))
+    loop = lambda spx, B, nsteps, dt, N, tsp, Pp: ls("closed_loop", "f64", cp, spx, B, nsteps, dt, N, tsp, 0, Pp, 0, 0, 0, 0, 0, p(t), p(z3), p(z3), p(z3), p(z3),
+                                                     p(state), 0, 0, -1, None, 1, 0, 0, 0, 0, 0)
+    assert loop(sp, 2, 3, 0.01, 2, p(ts), p(P)) == 0
+    assert loop(sp, 0, 3, 0.01, 2, 0, 0) == 0 and loop(sp, 2, 0, 0.01, 2, 0, 0) == 0      # nothing to do
+    assert loop(sp, 2, 3, 0.01, 2, 0, p(P)) == -1 and loop(sp, 2, 3, 0.01, 2, p(ts), 0) == -1
+    assert loop(sp, 2, -1, 0.01, 2, p(ts), p(P)) == -3 and loop(sp, 2, 3, 0.01, 0, p(ts), p(P)) == -3
+    assert loop(sp, 2, 3, float("inf"), 2, p(ts), p(P)) == -4
+    bads = lib.simulator_default_params(); bads.inertia[2] = 0.0
+    assert loop(bads, 2, 3, 0.01, 2, p(ts), p(P)) == -4
+    assert ls("closed_loop", "f64", cp, sp, 2, 3, 0.01, 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(t), p(z3), p(z3), p(z3), p(z3), p(state), 0, 0, 1, None, 1, 0, 0, 0, 0, 0) == -1   # gust step without a gust vector
+    assert ls("simulator_step", "f64", sp, 2, 0.01, p(th), p(tq), 0, 0, p(t), p(z3), p(z3), p(z3), p(z3), 0) == 0
+    assert ls("simulator_step", "f64", sp, 2, 0.01, 0, p(tq), 0, 0, p(t), p(z3), p(z3), p(z3), p(z3), 0) == -1
+    assert ls("control_plan", "f64", cp, 2, p(t), p(t), p(z3), p(z3), p(z3), p(z3), 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(state), p(th), p(tq), 0, 0, 0, 0, 0) == 0
+    assert ls("control_plan", "f64", cp, 2, p(t), 0, p(z3), p(z3), p(z3), p(z3), 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(state), p(th), p(tq), 0, 0, 0, 0, 0) == -1
+    assert lib._dll.se3mpc_set_solver_variant(2) == -3 and lib._dll.se3mpc_set_solver_variant(0) == 0
