@@ -17,6 +17,11 @@ def pytest_configure(config):
     from dart_planner_amd.planning import se3_mpc_planner as mod
     ops = Ops(TorchCpuBackend(), capi.Library(build_emu.build()))
     mod.SE3MPCPlanner._get_ops = lambda self: ops
+    # the controller and simulator mirrors run on the device too: same emulated library
+    from dart_planner_amd.control import geometric_controller as ctl
+    from dart_planner_amd.utils import drone_simulator as sim
+    ctl.GeometricController._get_ops = lambda self: ops
+    sim.DroneSimulator._get_ops = lambda self: ops
     # the mapper mirror builds its device table through Ops(): hand it the emulated library too
     from dart_planner_amd import voxel_map
     real_init = voxel_map.DeviceVoxelMap.__init__
