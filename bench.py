@@ -677,6 +677,19 @@ def iterated_leg(torch, ops, dev, B, N, min_ms, ks=(0, 1, 4, 16, 64)):
                              "rollouts_per_s": B * (K + 1) / (us * 1e-6), "hbm_bytes_per_launch": hbm * B,
                              "hbm_GB_per_s": hbm * B / (us * 1e-6) / 1e9,
                              "rollout_equivalent_GB_per_s": 4 * (6 * N + 10) * B * (K + 1) / (us * 1e-6) / 1e9})
+    # the same loop over 64 independent batches per launch (grid.y), K = 16: the chip is full, the bound is VALU issue
+    S, K = 64, 16
+    if ring >= 2 * S:
+        nl = ring // S
+        body = lambda: [ops.rollout_iterate(prm, p0[i * S:(i + 1) * S], v0[i * S:(i + 1) * S], goal[i * S:(i + 1) * S], T[i * S:(i + 1) * S], K, step,
+                                            out=(Tout[i * S:(i + 1) * S], cost[i * S:(i + 1) * S], grad[i * S:(i + 1) * S])) for i in range(nl)]
+        body(); torch.cuda.synchronize()
+        graph = capture(torch, dev, body)
+        ms1 = device_ms(torch, graph.replay, 2)
+        us = device_ms(torch, graph.replay, max(2, math.ceil(min_ms / max(ms1, 1e-6)))) / nl * 1e3
+        del graph
+        out["batched_64_K16"] = {"launch_us": us, "rollouts_per_launch": B * S * (K + 1), "rollouts_per_s": B * S * (K + 1) / (us * 1e-6),
+                                 "us_per_iteration_per_batch": us / S / (K + 1), "hbm_GB_per_s": (4 * (9 + 3 * N) + 4 * (1 + 6 * N)) * B * S / (us * 1e-6) / 1e9}
     out["note"] = ("rollout_equivalent_GB_per_s prices every in-register rollout at the 4*(6N+10) B a stand-alone launch would move; it may "
                    "exceed the HBM peak -- the iterations in between touch no memory -- and is NOT a roofline fraction; the bound of this "
                    "kernel is the dependent-instruction latency of the 2N-step sweep per iteration")

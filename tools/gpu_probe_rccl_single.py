@@ -11,7 +11,8 @@ torch.cuda.set_device(dev)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 from dart_planner_amd import distributed as D
-keys = torch.tensor([(0x80000000 | 77) << 32 | 5, (0x7F000000) << 32 | 9], dtype=torch.int64, device=dev)
+import numpy as np
+keys = torch.from_numpy(np.array([(0x80000000 | 77) << 32 | 5, (0x7F000000) << 32 | 9], dtype=np.uint64).view(np.int64).copy()).to(dev)
 ref = keys.clone()
 _orig = dist.get_world_size
 dist.get_world_size = lambda *a, **k: 2          # force the collective branch although the world has one rank
