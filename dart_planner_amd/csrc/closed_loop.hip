@@ -260,9 +260,13 @@ __device__ void control_step(const CtrlDev<R>& c, CtrlRegs<R>& s, double t, cons
 // OnboardController._interpolate_trajectory (onboard.py:43-93).  ts: N timestamps (double); P, V, A: [N][3] rows (V, A may be null).
 template <typename R>
 __device__ __forceinline__ void sample_plan(double t, int N, const double* __restrict__ ts, const R* __restrict__ P, const R* __restrict__ V,
-                                            const R* __restrict__ A, R tp[3], R tv[3], R ta[3]) {
-  int idx = 0;                                                                    // np.searchsorted(ts, t): first i with ts[i] >= t
+                                            const R* __restrict__ A, R tp[3], R tv[3], R ta[3], int& hint) {
+  // np.searchsorted(ts, t): first i with ts[i] >= t.  `hint` = the answer for an earlier (smaller or equal) t of the same sorted plan, 0
+  // otherwise: the closed loop's clock only moves forward, so the scan resumes where the last step stopped instead of paying up to N
+  // dependent loads per step.
+  int idx = hint;
   while (idx < N && ts[idx] < t) ++idx;
+  hint = idx;
   int i1, i2;
   R f = (R)0;
   if (idx == 0) { i1 = i2 = 0; }                                                  // :51-63
@@ -314,8 +318,9 @@ control_kernel(CtrlDev<R> c, int B, const double* __restrict__ time, const R* __
   R p[3], v[3], a[3], w[3], dp[3], dv[3], da[3];
   for (int i = 0; i < 3; ++i) { p[i] = pos[3 * b + i]; v[i] = vel[3 * b + i]; a[i] = att[3 * b + i]; w[i] = omega[3 * b + i]; }
   if (sample_time != nullptr) {                       // compute_control_from_trajectory: the target is the plan sampled at sample_time
+    int hint = 0;
     sample_plan<R>(sample_time[b], N, timestamps + (size_t)b * ts_stride, P + (size_t)b * strideP,
-                   V != nullptr ? V + (size_t)b * strideV : nullptr, A != nullptr ? A + (size_t)b * strideA : nullptr, dp, dv, da);
+                   V != nullptr ? V + (size_t)b * strideV : nullptr, A != nullptr ? A + (size_t)b * strideA : nullptr, dp, dv, da, hint);
     if (target != nullptr) for (int i = 0; i < 3; ++i) { target[9 * b + i] = dp[i]; target[9 * b + 3 + i] = dv[i]; target[9 * b + 6 + i] = da[i]; }
   } else {
     for (int i = 0; i < 3; ++i) { dp[i] = dpos[3 * b + i]; dv[i] = dvel[3 * b + i]; da[i] = dacc != nullptr ? dacc[3 * b + i] : (R)0; }
@@ -358,7 +363,7 @@ closed_loop_kernel(CtrlDev<R> c, SimDev<R> m, int B, int nsteps, double sim_dt, 
   const R* Ab = A != nullptr ? A + (size_t)b * strideA : nullptr;
   const double ts_last = ts[N - 1];
   const R dt = (R)sim_dt;
-  int taken = 0;
+  int taken = 0, hint = 0;
   bool active = true;
   for (int step = 0; step < nsteps; ++step) {
     if (stop_at_plan_end && t > ts_last) active = false;                          // contract tests :130-131 / :263-264 (`break`)
@@ -370,7 +375,8 @@ closed_loop_kernel(CtrlDev<R> c, SimDev<R> m, int B, int nsteps, double sim_dt, 
     R th = (R)NAN, tq[3] = {(R)NAN, (R)NAN, (R)NAN};
     if (active) {
       R tp[3], tv[3], ta[3];
-      sample_plan<R>(t, N, ts, Pb, Vb, Ab, tp, tv, ta);
+      if (!(sim_dt > 0.0)) hint = 0;                                           // a clock that does not advance: search from the start
+      sample_plan<R>(t, N, ts, Pb, Vb, Ab, tp, tv, ta, hint);
       int fl;
       control_step<R>(c, s, t, p, v, a, w, tp, tv, ta, (R)0, (R)0, th, tq, fl);
       if (step == gust_step) { wd[0] = gx; wd[1] = gy; wd[2] = gz; }              // the gust of contract test :293-296

@@ -26,6 +26,7 @@ import tempfile
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.environ.get("SE3MPC_GOLDEN_OUT", HERE)      # tests/test_golden_reproducible.py writes to a scratch directory
 REF_SRC = "/root/reference/src"
 
 PINT_INIT = '''
@@ -161,8 +162,8 @@ def main():
                              maxiter=int(pl.se3_config.max_iterations),
                              nit=int(res.nit), nfev=int(res.nfev), status=int(res.status),
                              success=bool(res.success), message=str(res.message)))
-        np.savez_compressed(os.path.join(HERE, "solve_cases.npz"), **out)
-        with open(os.path.join(HERE, "solve_cases.json"), "w") as f:
+        np.savez_compressed(os.path.join(OUT_DIR, "solve_cases.npz"), **out)
+        with open(os.path.join(OUT_DIR, "solve_cases.json"), "w") as f:
             json.dump(dict(scipy=scipy.__version__, numpy=np.__version__, cases=meta), f, indent=1)
 
         # ------------------------------------------------- direct calls of path functions
@@ -242,8 +243,8 @@ def main():
             tr = Trajectory(timestamps=np.arange(5) * 0.1, positions=P, velocities=V)
             out[f"v{j}_P"], out[f"v{j}_V"] = P, V
             valid_cases.append(dict(key=f"v{j}_", tag=tag, valid=bool(pl.is_plan_valid(tr))))
-        np.savez_compressed(os.path.join(HERE, "path_functions.npz"), **out)
-        with open(os.path.join(HERE, "path_functions.json"), "w") as f:
+        np.savez_compressed(os.path.join(OUT_DIR, "path_functions.npz"), **out)
+        with open(os.path.join(OUT_DIR, "path_functions.json"), "w") as f:
             json.dump(dict(scipy=scipy.__version__, numpy=np.__version__, cases=meta, valid=valid_cases,
                            constants=dict(mass=float(pl.mass), gravity=float(pl.gravity),
                                           hover=float(pl.hover_thrust), default_dt=1.0 / 400.0)), f, indent=1)
@@ -275,8 +276,8 @@ def main():
             out[k + "spheres"] = np.concatenate([chosen, np.ones((len(chosen), 1))], axis=1)
             meta.append(dict(key=k, centre=centre, size=size, resolution=0.5, target=target, n_occupied=int(occupied_points.shape[0]),
                              n_spheres=int(len(chosen)), num_cells=int(grid.shape[0])))
-        np.savez_compressed(os.path.join(HERE, "mapper_spheres.npz"), **out)
-        with open(os.path.join(HERE, "mapper_spheres.json"), "w") as f:
+        np.savez_compressed(os.path.join(OUT_DIR, "mapper_spheres.npz"), **out)
+        with open(os.path.join(OUT_DIR, "mapper_spheres.json"), "w") as f:
             json.dump(dict(cases=meta), f, indent=1)
         # ---------------------------------------------- wire format: the reference's own serializer
         from dart_planner.communication.secure_serializer import SecureSerializer
@@ -292,9 +293,9 @@ def main():
             raw = ser.serialize(pl_)
             back = ser.deserialize(raw)
             wire.append(dict(raw=raw.decode("utf-8")))
-        with open(os.path.join(HERE, "wire_messages.json"), "w") as f:
+        with open(os.path.join(OUT_DIR, "wire_messages.json"), "w") as f:
             json.dump(dict(secret="golden-secret-key", messages=wire), f, indent=1)
-        print("wrote", os.listdir(HERE))
+        print("wrote", os.listdir(OUT_DIR))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

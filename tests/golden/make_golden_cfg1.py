@@ -20,6 +20,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.environ.get("SE3MPC_GOLDEN_OUT", HERE)      # tests/test_golden_reproducible.py writes to a scratch directory
 sys.path.insert(0, HERE)
 from make_golden import _install_standins  # noqa: E402
 
@@ -63,9 +64,9 @@ def main():
                 traj[k].append(np.array(getattr(tr, k), float))
         out.update(goals_used=np.array(used), x=np.array(X), fun=np.array(fun), info=np.array(info, dtype=np.int32),
                    bounds=captured["bounds"], **{k: np.array(v) for k, v in traj.items()})
-        np.savez_compressed(os.path.join(HERE, "cfg1_solves.npz"), **out)
+        np.savez_compressed(os.path.join(OUT_DIR, "cfg1_solves.npz"), **out)
         c = pl.se3_config
-        with open(os.path.join(HERE, "cfg1_solves.json"), "w") as f:
+        with open(os.path.join(OUT_DIR, "cfg1_solves.json"), "w") as f:
             json.dump(dict(scipy=scipy.__version__, numpy=np.__version__, n=len(goals), N=int(c.prediction_horizon), dt=float(c.dt),
                            max_velocity=float(c.max_velocity), max_acceleration=float(c.max_acceleration),
                            tol=float(c.convergence_tolerance), maxiter=int(c.max_iterations),

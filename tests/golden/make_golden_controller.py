@@ -23,6 +23,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.environ.get("SE3MPC_GOLDEN_OUT", HERE)      # tests/test_golden_reproducible.py writes to a scratch directory
 sys.path.insert(0, HERE)
 from make_golden import _install_standins  # noqa: E402
 
@@ -228,8 +229,8 @@ def main():
         meta["loops"] = loops
         meta["T0"] = T0
 
-        np.savez_compressed(os.path.join(HERE, "controller_cases.npz"), **out)
-        with open(os.path.join(HERE, "controller_cases.json"), "w") as f:
+        np.savez_compressed(os.path.join(OUT_DIR, "controller_cases.npz"), **out)
+        with open(os.path.join(OUT_DIR, "controller_cases.json"), "w") as f:
             json.dump(meta, f, indent=1)
         print("wrote controller_cases.npz / .json:", len(seqs), "sequences,", len(loops), "closed loops")
     finally:

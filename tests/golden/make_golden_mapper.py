@@ -18,6 +18,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+OUT_DIR = os.environ.get("SE3MPC_GOLDEN_OUT", HERE)      # tests/test_golden_reproducible.py writes to a scratch directory
 sys.path.insert(0, HERE)
 from make_golden import _install_standins  # noqa: E402
 
@@ -132,10 +133,10 @@ def main():
             vox = m._trace_ray(np.array(start, float), np.array(d, float), dist)
             out[f"r{i:02d}_voxels"] = np.array(vox, dtype=np.int64).reshape(-1, 3)
             meta["rays"].append(dict(key=f"r{i:02d}_", resolution=res, start=start, direction=d, distance=dist, n=len(vox)))
-        np.savez_compressed(os.path.join(HERE, "mapper_map.npz"), **out)
-        with open(os.path.join(HERE, "mapper_map.json"), "w") as f:
+        np.savez_compressed(os.path.join(OUT_DIR, "mapper_map.npz"), **out)
+        with open(os.path.join(OUT_DIR, "mapper_map.json"), "w") as f:
             json.dump(meta, f, indent=1)
-        print("wrote mapper_map.npz", os.path.getsize(os.path.join(HERE, "mapper_map.npz")), "bytes;", len(out), "arrays")
+        print("wrote mapper_map.npz", os.path.getsize(os.path.join(OUT_DIR, "mapper_map.npz")), "bytes;", len(out), "arrays")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
