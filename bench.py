@@ -727,8 +727,21 @@ def closed_loop_leg(torch, ops, dev):
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t0)
         el = float(np.median(ts))
+        replay = mc.capture(S, dtype, cycles, substeps, sim_dt)
+        replay(p0, v0, goal, wind); torch.cuda.synchronize()
+        tg = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            outg = replay(p0, v0, goal, wind)
+            torch.cuda.synchronize()
+            tg.append(time.perf_counter() - t0)
+        eg = float(np.median(tg))
         res[name] = {"wall_ms_per_monte_carlo": el * 1e3, "runs_per_s": S / el, "plans_per_s": S * cycles / el,
-                     "control_steps_per_s": S * cycles * substeps / el, "finite": bool(torch.isfinite(pos).all())}
+                     "control_steps_per_s": S * cycles * substeps / el, "finite": bool(torch.isfinite(pos).all()),
+                     "hipgraph_wall_ms_per_monte_carlo": eg * 1e3, "hipgraph_runs_per_s": S / eg,
+                     "hipgraph_equals_eager": bool(torch.equal(outg["pos"], pos))}
+        del replay
     return {"what": f"{S} closed-loop runs x {cycles} planning cycles x {substeps} control+simulator steps (horizon-6 plans, DI defaults), "
                     "2 launches per cycle, no host arithmetic", **res}
 

@@ -44,3 +44,31 @@ class ClosedLoopMonteCarlo:
             if log:
                 logs.append((sol, out))
         return dict(pos=pos, vel=vel, att=att, omega=om, time=time, controller_state=st, logs=logs)
+
+    def capture(self, B: int, dtype, cycles: int, substeps: int, sim_dt: float, with_wind: bool = True):
+        """The whole Monte-Carlo (2 x `cycles` kernel launches + the plan stamps) captured ONCE into a hipGraph; each call of the
+        returned function copies new initial conditions into the graph's static inputs, replays it and returns the static outputs
+        (overwritten by the next call).  Removes the per-launch host cost (~30 us of Python + launch per call, 66 calls per run)."""
+        import torch
+        dev = self.ops.be.device
+        static = dict(p0=torch.zeros(B, 3, dtype=dtype, device=dev), v0=torch.zeros(B, 3, dtype=dtype, device=dev),
+                      goal=torch.zeros(B, 3, dtype=dtype, device=dev), wind=torch.zeros(B, 3, dtype=dtype, device=dev) if with_wind else None)
+        run = lambda: self.run(static["p0"], static["v0"], static["goal"], cycles, substeps, sim_dt, wind=static["wind"])
+        run()                                                    # warm-up outside the capture (library load, allocator pools)
+        torch.cuda.synchronize()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                out = run()
+        torch.cuda.current_stream().wait_stream(side)
+
+        def replay(p0, v0, goal, wind=None):
+            static["p0"].copy_(p0); static["v0"].copy_(v0); static["goal"].copy_(goal)
+            if with_wind:
+                static["wind"].copy_(wind) if wind is not None else static["wind"].zero_()
+            graph.replay()
+            return out
+        replay.graph = graph
+        return replay

@@ -21,6 +21,10 @@
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
 
+#ifndef SE3MPC_SOLVE_WAVES
+#define SE3MPC_SOLVE_WAVES 2      // resident wavefronts per SIMD the register allocation leaves room for (J <= 5); 3 was measured slower (spills)
+#endif
+
 namespace se3mpc {
 
 constexpr double kEps = 2.220446049250313e-16;   // DBL_EPSILON (epsmch)
@@ -396,7 +400,7 @@ struct ColTag { static constexpr int value = C; };
 // 2nd launch-bounds argument = wavefronts per SIMD the register allocation must leave room for: two
 // resident solves per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
 template <typename IO, int J>
-__global__ void __launch_bounds__(64, (J <= 5 ? 2 : 1))
+__global__ void __launch_bounds__(64, (J <= 5 ? SE3MPC_SOLVE_WAVES : 1))
 solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict__ v0g, const IO* __restrict__ goalg,
              const IO* __restrict__ x0g, IO* __restrict__ Xg, se3mpc_solve_info* __restrict__ infog,
              IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg) {

@@ -239,3 +239,27 @@ def test_device_plan_travels_in_the_reference_envelope(gpu_ops):
     assert np.max(np.abs(back.positions[0] - [2.1897985430479023, 2.1897985430479023, 3.1679005576174233])) <= 1e-9
     # and this package's own receiving side agrees
     assert np.array_equal(trajectory_from_wire(ser.deserialize(raw)["trajectory"]).positions, tr.positions)
+
+
+def test_monte_carlo_hipgraph_replay_equals_eager(gpu_ops):
+    """The library never allocates or synchronises, so the whole receding-horizon Monte-Carlo (66 launches) captures into one hipGraph;
+    a replay with new initial conditions equals the eager run bit for bit."""
+    import torch
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd.control.closed_loop import ClosedLoopMonteCarlo
+    ops = gpu_ops
+    dev = ops.be.device
+    S, cycles, substeps, sim_dt = 512, 8, 15, 0.01
+    mc = ClosedLoopMonteCarlo(ops, Params.reference_defaults())
+    replay = mc.capture(S, torch.float32, cycles, substeps, sim_dt)
+    g = torch.Generator(device=dev); g.manual_seed(11)
+    for trial in range(2):
+        p0 = torch.tensor([0.0, 0.0, 2.0], device=dev).repeat(S, 1) + 0.3 * torch.randn(S, 3, device=dev, generator=g)
+        v0 = 0.3 * torch.randn(S, 3, device=dev, generator=g)
+        goal = (torch.tensor([8.0, 0.0, 5.0], device=dev) + torch.randn(S, 3, device=dev, generator=g)).contiguous()
+        wind = torch.randn(S, 3, device=dev, generator=g)
+        eager = mc.run(p0, v0, goal, cycles, substeps, sim_dt, wind=wind)
+        out = replay(p0, v0, goal, wind)
+        torch.cuda.synchronize()
+        for k in ("pos", "vel", "att", "omega", "time", "controller_state"):
+            assert torch.equal(out[k], eager[k]), (trial, k)
