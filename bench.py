@@ -654,7 +654,7 @@ def iterated_leg(torch, ops, dev, B, N, min_ms, ks=(0, 1, 4, 16, 64)):
     from dart_planner_amd.capi import Params
     prm = Params.reference_defaults(horizon=N)
     slot = 4 * B * ((9 + 3 * N) + (1 + 6 * N))
-    ring = max(2, math.ceil(320 * 2 ** 20 / slot))
+    ring = max(128, math.ceil(320 * 2 ** 20 / slot))                 # >= two 64-batch launches on disjoint slots
     p0, v0, goal, T, cost, grad = make_ring(torch, dev, B, N, ring, seed=77)
     Tout = torch.empty_like(T)
     step = 0.9
