@@ -1,0 +1,64 @@
+"""GPU box: the consumer-side kernels against the NumPy oracle over every controller configuration the reference can be put in --
+7 tuning profiles x 2 anti-windup methods x 4 yaw-singularity fallbacks (incl. an unknown method name) -- random drones, plans, winds, gusts,
+invalid time steps; f64 step-by-step (states and commands <= 1e-8 over 60 steps), f32 by the fraction of drones that stay within 5e-2 of
+the f64 oracle.  One JSON line per configuration and a total.  usage: python tools/gpu_fuzz_controller.py [drones_per_config]"""
+import json, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch
+from dart_planner_amd.capi import ControllerParams, SimulatorParams
+from dart_planner_amd.control.geometric_controller import GeometricControllerConfig, TUNING_PROFILES, GeometricController
+from dart_planner_amd.ops import Ops, TorchBackend
+from oracle import controller_oracle as co
+import controller_checks as cc
+
+ops = Ops(TorchBackend("cuda:0"))
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+dev = ops.be.device
+tot = dict(configs=0, drones=0, worst_f64=0.0, f32_within_5e2=1.0)
+t0 = time.time()
+for pi, prof in enumerate(TUNING_PROFILES):
+    for aw in ("clamping", "back_calculation"):
+        for fb in ("skip_yaw", "default_heading", "maintain_current", "something_else"):
+            conf = GeometricControllerConfig()
+            GeometricController._apply_tuning_profile(None, conf, prof)
+            conf.anti_windup_method, conf.yaw_singularity_fallback_method, conf.default_heading_yaw = aw, fb, 0.4
+            ocfg = co.ControllerConfig(**{k: getattr(conf, k) for k in co.ControllerConfig.__dataclass_fields__})
+            cp = ControllerParams.from_config(conf)
+            rng = np.random.default_rng(1000 * pi + 17 * len(aw) + len(fb))
+            N, nsteps = 10, 60
+            ts, P, V, A = cc.random_plans(rng, B, N, 77.0, 0.05)
+            TS = np.tile(ts, (B, 1)) - rng.choice([0.0, 0.1, 0.4], (B, 1))
+            spread = rng.choice([0.05, 0.5, 4.0], (B, 1))                      # near the plan, off it, far off it (saturation, tilt limit)
+            pos = P[:, 0] + rng.normal(0, 1, (B, 3)) * spread; vel = V[:, 0] + rng.normal(0, 1, (B, 3)) * spread
+            att = rng.normal(0, 0.3, (B, 3)); om = rng.normal(0, 0.5, (B, 3)); t = np.full(B, 77.0)
+            wind = rng.normal(0, 2.0, (B, 3))
+            sim_dt = float(rng.choice([0.01, 0.0025, 0.05]))
+            sim = co.SimulatorConfig(max_thrust=float(rng.choice([20.0, 5.0])), max_torque=float(rng.choice([10.0, 2.0])))
+            sp = SimulatorParams.reference_defaults(max_thrust=sim.max_thrust, max_torque=sim.max_torque)
+            gust = (nsteps // 3, [5.0, -2.0, 1.0])
+            res = {}
+            for dt_ in (np.float64, np.float32):
+                r = lambda a: np.asarray(a).astype(dt_).astype(float)
+                fin, log = co.closed_loop(ocfg, sim, co.ControllerState(B, ocfg), r(pos), r(vel), r(att), r(om), t, TS, r(P), r(V), r(A), nsteps, sim_dt,
+                                          wind=r(wind), gust_step=gust[0], gust_wind=gust[1])
+                d = lambda a, ty=dt_: torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(ty))).to(dev)
+                st = ops.controller_state(cp, B)
+                out = ops.closed_loop(cp, sp, st, d(t, np.float64), d(pos), d(vel), d(att), d(om), d(TS, np.float64), d(P), d(V), d(A), nsteps=nsteps,
+                                      sim_dt=sim_dt, wind=d(wind), gust=gust, log=True)
+                ls = out["log_state"].cpu().numpy().astype(float)
+                ref = np.concatenate([log["pos"], log["vel"], log["att"], log["omega"]], axis=2)
+                assert np.array_equal(out["steps_taken"].cpu().numpy(), log["active"].sum(0))
+                err = np.max(np.abs(ls - ref), axis=(0, 2))
+                res[np.dtype(dt_).name] = err
+                if dt_ == np.float64:
+                    lc = out["log_cmd"].cpu().numpy()
+                    act = log["active"]
+                    assert np.nanmax(np.abs(lc[..., 0][act] - log["thrust"][act])) <= 1e-8
+            w64 = float(res["float64"].max()); ok32 = float(np.mean(res["float32"] <= 5e-2))
+            assert w64 <= 1e-8, (prof, aw, fb, w64)
+            tot["configs"] += 1; tot["drones"] += 2 * B; tot["worst_f64"] = max(tot["worst_f64"], w64); tot["f32_within_5e2"] = min(tot["f32_within_5e2"], ok32)
+            print(json.dumps(dict(profile=prof, anti_windup=aw, fallback=fb, sim_dt=sim_dt, drones=B, steps=nsteps, worst_state_error_f64=w64,
+                                  f32_median_error=float(np.median(res["float32"])), f32_fraction_within_5e2=ok32)), flush=True)
+tot["seconds"] = round(time.time() - t0, 1)
+print(json.dumps(tot))
