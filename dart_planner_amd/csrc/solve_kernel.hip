@@ -21,6 +21,15 @@
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
 
+// -DSE3MPC_SOLVE_PROFILE (tools/gpu_profile_solve_sections.sh, never the shipped build): per-section cycle sums of every wavefront, written over
+// the first 64 bytes of its `thrust` output row.  Sections: 0 start-up + first evaluation, 1 later evaluations, 2 Cauchy point, 3 subspace
+// minimisation, 4 line search without its evaluations, 5 convergence tests + BFGS update, 6 results, 7 total.
+#ifdef SE3MPC_SOLVE_PROFILE
+#define SE3MPC_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tlast; tlast = now_; }
+#else
+#define SE3MPC_TICK(i)
+#endif
+
 #ifndef SE3MPC_SOLVE_WAVES
 #define SE3MPC_SOLVE_WAVES 2      // resident wavefronts per SIMD the register allocation leaves room for (J <= 5); 3 was measured slower (spills)
 #endif
@@ -438,8 +447,24 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   const double goal1 = q.has_goal ? (double)goalg[pb * 3 + 1] : 0.0;
   const double goal2 = q.has_goal ? (double)goalg[pb * 3 + 2] : 0.0;
   auto goal_of = [&](int cd) { const int a = (cd >> 2) & 3; return a == 0 ? goal0 : (a == 1 ? goal1 : goal2); };
+  // the state too is fetched here, at wave-uniform addresses, next to the goal: nine independent loads in flight at once.  (Inside the
+  // per-element branches below each element's load was issued only when its branch was reached: J dependent HBM round trips.)
+  const bool cold = x0g == nullptr;
+  const double ps0 = cold ? (double)p0g[pb * 3 + 0] : 0.0, ps1 = cold ? (double)p0g[pb * 3 + 1] : 0.0, ps2 = cold ? (double)p0g[pb * 3 + 2] : 0.0;
+  const double vs0 = cold ? (double)v0g[pb * 3 + 0] : 0.0, vs1 = cold ? (double)v0g[pb * 3 + 1] : 0.0, vs2 = cold ? (double)v0g[pb * 3 + 2] : 0.0;
 
+#ifdef SE3MPC_SOLVE_PROFILE
+  unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  const unsigned long long tstart = tlast;
+#endif
   // ---- cold start (planner.py:329-359) or caller x0, projected into the box (L-BFGS-B `active`)
+  double xw[J];
+#pragma unroll
+  for (int j = 0; j < J; ++j) {
+    const int i = lane + kWave * j;
+    xw[j] = (!cold && i < n) ? (double)x0g[(size_t)pb * n + i] : 0.0;
+  }
 #pragma unroll
   for (int j = 0; j < J; ++j) {
     const int i = lane + kWave * j;
@@ -449,11 +474,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     double xv = 0.0;
     const int blk = code[j] & 3, a = (code[j] >> 2) & 3;
     if (blk != 3) {
-      if (x0g != nullptr) {
-        xv = (double)x0g[(size_t)pb * n + i];
+      if (!cold) {
+        xv = xw[j];
       } else {
         const int r = i - blk * 3 * N, k = r / 3;
-        const double pa = (double)p0g[pb * 3 + a], va = (double)v0g[pb * 3 + a], ga = goal_of(code[j]);
+        const double pa = a == 0 ? ps0 : (a == 1 ? ps1 : ps2), va = a == 0 ? vs0 : (a == 1 ? vs1 : vs2), ga = goal_of(code[j]);
         const double denom = (double)(N - 1 > 1 ? N - 1 : 1);
         if (blk == 0) {
           const double alpha = (double)k / denom;
@@ -477,7 +502,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   // nfev counts like scipy's ScalarFunction: asking again for the x evaluated last (a line search
   // whose steps shrank below rounding) returns the same (f, g) and is not counted.
   int nfev = 0;
-  auto eval_fg = [&]() -> double {
+  // with_gd: also return g(x)'d, its reduction interleaved with the objective's (the line search wants both)
+  double gd_fused = 0.0;
+  auto eval_fg = [&](bool with_gd = false) -> double {
     bool moved = false;
 #pragma unroll
     for (int j = 0; j < J; ++j) moved = moved || !(x[j] == xlast[lane + kWave * j]);
@@ -509,6 +536,15 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       }
       part += fj;
       g[j] = gj;
+    }
+    if (with_gd) {
+      double gdp = 0.0;
+#pragma unroll
+      for (int j = 0; j < J; ++j) gdp += g[j] * d[j];
+      double r2[2] = {part, gdp};
+      wave_sum_n<2>(r2);
+      gd_fused = r2[1];
+      return r2[0];
     }
     return wave_sum(part);
   };
@@ -545,6 +581,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 
   if (sbgnrm <= q.pgtol) { task = SE3MPC_TASK_CONV_PGTOL; status = 0; }
 
+  SE3MPC_TICK(0)
   int guard = 0;                           // every pass either ends an iteration or drops the memory; bounded anyway
   while (task == 0) {
     if (++guard > 4 * (q.maxiter + 8)) { task = SE3MPC_TASK_ABNORMAL; status = 2; break; }
@@ -612,7 +649,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         double a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
-        a1 = wave_sum(a1); a2 = wave_sum(a2);
+        double r2[2] = {a1, a2};
+        wave_sum_n<2>(r2);
+        a1 = r2[0]; a2 = r2[1];
         if (lane == 0) { pv[c] = a1; pv[col + c] = theta * a2; cv[c] = 0.0; cv[col + c] = 0.0; }
       }
       __syncthreads();
@@ -752,6 +791,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     }
     if (info != 0) { col = 0; theta = 1.0; iupdat = 0; continue; }   // singular middle matrix: refresh memory
 
+    SE3MPC_TICK(2)
     // ===================================================================== subspace minimization
     int nfree_p = 0;
 #pragma unroll
@@ -769,6 +809,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           for (int i = 0; i < 2 * C; ++i)
 #pragma unroll
             for (int k = 0; k < 2 * C; ++k) wnr[i][k] = 0.0;
+          // all C*C cells' partial sums first, then ONE interleaved reduction of the 3 sums each cell needs (yzzy, saas for the
+          // lower-left half, and the cross term: sa_y below the diagonal, sz_y on and above it)
+          double sums[3 * C * C];
 #pragma unroll
           for (int iy = 0; iy < C; ++iy) {
 #pragma unroll
@@ -781,13 +824,20 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
                 if (fr) { yzzy += wyi * wyj; sz_y += wsi * wyj; }
                 else { saas += wsi * wsj; sa_y += wsi * wyj; }
               }
+              sums[3 * (iy * C + jy) + 0] = yzzy; sums[3 * (iy * C + jy) + 1] = saas; sums[3 * (iy * C + jy) + 2] = (jy < iy) ? sa_y : sz_y;
+            }
+          }
+          wave_sum_n<3 * C * C>(sums);
+#pragma unroll
+          for (int iy = 0; iy < C; ++iy) {
+#pragma unroll
+            for (int jy = 0; jy < C; ++jy) {
+              const double yzzy = sums[3 * (iy * C + jy) + 0], saas = sums[3 * (iy * C + jy) + 1], cross = sums[3 * (iy * C + jy) + 2];
               if (jy <= iy) {
-                yzzy = wave_sum(yzzy); saas = wave_sum(saas);
                 wnr[jy][iy] = yzzy / theta + (jy == iy ? sy[iy * m + iy] : 0.0);
                 wnr[C + jy][C + iy] = saas * theta;
               }
-              if (jy < iy) wnr[jy][C + iy] = -wave_sum(sa_y);
-              else wnr[jy][C + iy] = wave_sum(sz_y);
+              wnr[jy][C + iy] = (jy < iy) ? -cross : cross;
             }
           }
           int inf = formk_factor_regs<C>(wnr);
@@ -816,8 +866,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
             for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
-            wr[c] = wave_sum(a1); wr[C + c] = theta * wave_sum(a2);
+            wr[c] = a1; wr[C + c] = a2;
           }
+          wave_sum_n<2 * C>(wr);
+#pragma unroll
+          for (int c = 0; c < C; ++c) wr[C + c] = theta * wr[C + c];
           int inf2 = dtrsl_regs<2 * C>(wnr, wr, true);
           if (!inf2) {
 #pragma unroll
@@ -893,7 +946,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             double a1 = 0.0, a2 = 0.0;
   #pragma unroll
             for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
-            a1 = wave_sum(a1); a2 = wave_sum(a2);
+            double r2[2] = {a1, a2};
+            wave_sum_n<2>(r2);
+            a1 = r2[0]; a2 = r2[1];
             if (lane == 0) { wv[c] = a1; wv[col + c] = theta * a2; }
           }
           __syncthreads();
@@ -985,11 +1040,15 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       if (info != 0) { col = 0; theta = 1.0; iupdat = 0; continue; }
     }
 
+    SE3MPC_TICK(3)
     // ===================================================================== line search (lnsrlb)
-    double dtdp = 0.0;
+    double dtdp = 0.0, gd0p = 0.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) { d[j] = z[j] - x[j]; dtdp += d[j] * d[j]; }
-    const double dtd = wave_sum(dtdp);
+    for (int j = 0; j < J; ++j) { d[j] = z[j] - x[j]; dtdp += d[j] * d[j]; gd0p += g[j] * d[j]; }
+    double r2[2] = {dtdp, gd0p};
+    wave_sum_n<2>(r2);
+    const double dtd = r2[0];
+    gd_fused = r2[1];                                         // g'd at the start of the search
     double stpmx;
     if (iter == 0) stpmx = 1.0;
     else {
@@ -1013,10 +1072,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     LineSearch ls;
     bool start = true;
     while (true) {
-      double gdp = 0.0;
-#pragma unroll
-      for (int j = 0; j < J; ++j) gdp += g[j] * d[j];
-      gd = wave_sum(gdp);
+      gd = gd_fused;                                          // reduced together with dtd (first pass) or with f (after an evaluation)
       if (ifun == 0) {
         gdold = gd;
         if (gd >= 0.0) { ls_info = -4; break; }
@@ -1034,8 +1090,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
         for (int j = 0; j < J; ++j) x[j] = stp * d[j] + xo[j];
       }
-      f = eval_fg();
+      SE3MPC_TICK(4)
+      f = eval_fg(true);
+      SE3MPC_TICK(1)
     }
+    SE3MPC_TICK(4)
     if (ls_info != 0 || iback >= q.maxls) {
       // restore the previous iterate
 #pragma unroll
@@ -1102,7 +1161,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           double a1 = 0.0, a2 = 0.0;
 #pragma unroll
           for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
-          syr[C - 1][c] = wave_sum(a1); ssr[c][C - 1] = wave_sum(a2);
+          double r2[2] = {a1, a2};
+          wave_sum_n<2>(r2);
+          syr[C - 1][c] = r2[0]; ssr[c][C - 1] = r2[1];
         }
         ssr[C - 1][C - 1] = (stp == 1.0) ? dtd : stp * stp * dtd;
         syr[C - 1][C - 1] = dr;
@@ -1162,6 +1223,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 
   }
 
+  SE3MPC_TICK(5)
   // ===================================================================== results
 #pragma unroll
   for (int j = 0; j < J; ++j) {
@@ -1231,6 +1293,15 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     if (ratesg != nullptr) { ratesg[o] = (IO)w0; ratesg[o + 1] = (IO)w1; ratesg[o + 2] = (IO)w2; }
     if (thrustg != nullptr) thrustg[(size_t)pb * N + lane] = (IO)mag;
   }
+#ifdef SE3MPC_SOLVE_PROFILE
+  __syncthreads();
+  SE3MPC_TICK(6)
+  tsec[7] = tlast - tstart;
+  if (lane == 0 && thrustg != nullptr && (size_t)N * sizeof(IO) >= 64) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(thrustg + (size_t)pb * N);
+    for (int i = 0; i < 8; ++i) dst[i] = tsec[i];
+  }
+#endif
 }
 
 static int g_solver_variant = 0;   // bit 0: published sequential Cauchy search also while the memory is empty

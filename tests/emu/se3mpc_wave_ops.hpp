@@ -19,6 +19,8 @@ inline T emu_wave_reduce(T v, OP op) {
   return acc;
 }
 inline double wave_sum(double v) { return emu_wave_reduce(v, [](double a, double b) { return a + b; }); }
+template <int K>
+inline void wave_sum_n(double (&v)[K]) { for (int k = 0; k < K; ++k) v[k] = wave_sum(v[k]); }
 inline double wave_max(double v) { return emu_wave_reduce(v, [](double a, double b) { return a > b ? a : b; }); }
 inline double wave_min(double v) { return emu_wave_reduce(v, [](double a, double b) { return a < b ? a : b; }); }
 inline uint32_t wave_min_u32(uint32_t v) { return emu_wave_reduce(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
