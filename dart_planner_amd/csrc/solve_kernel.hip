@@ -612,8 +612,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         } else {
           d[j] = neggi;
           f1p -= neggi * neggi;
-          if (neggi < 0.0) { tbp[j] = tl / (-neggi); ++nbr; }
-          else if (neggi > 0.0) { tbp[j] = tu / neggi; ++nbr; }
+          if (neggi != 0.0) {                                 // one division: tl / (-neggi) for a descending, tu / neggi for an ascending variable
+            tbp[j] = (neggi < 0.0 ? tl : tu) / fabs(neggi);
+            ++nbr;
+          }
         }
         z[j] = x[j];
       }
