@@ -715,7 +715,10 @@ rollout_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R*
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ float fma_r(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double fma_r(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// the same expression in the in-launch loop and in the stand-alone step kernel: one fused multiply-add, then the box
+// clamp(x, lo, hi) for lo <= hi as ONE instruction (v_med3): the median of (x, lo, hi); a NaN x comes back as lo or hi like fmin(fmax())
+__device__ __forceinline__ float clamp_r(float x, float lo, float hi) { return __builtin_amdgcn_fmed3f(x, lo, hi); }
+__device__ __forceinline__ double clamp_r(double x, double lo, double hi) { return fmin(fmax(x, lo), hi); }
+// the same expression in the stand-alone step kernel and in the memory-resident fallback: one fused multiply-add, then the box
 template <typename R>
 __device__ __forceinline__ R projected_update(R t, R g, R step, R lo, R hi) {
   return fmin(fmax(fma_r(-step, g, t), lo), hi);
@@ -762,35 +765,40 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
   };
   cost_first = (R)0;
   if (want_first && iters > 0) cost_first = forward_cost();
+  // Descent iterations in their leanest algebraically equal form (11 VALU per step instead of 17): the position error e = P - goal is
+  // rolled out directly (the goal is constant, so e obeys P's recurrence), the local part of the gradient is one fma
+  //   d/dT_k [wa acc^2 + wT (T - hover)^2] = gA T_k - gB,   gA = 2 wa / m^2 + 2 wT,  gB = 2 wa g / m + 2 wT hover,
+  // and the step is folded into the coefficients:  T <- clamp(T (1 - s gA) + s gB - s c_lp lamP - s c_lv lamV).
+  // Rounding differs from the evaluation passes' expressions by a few ulp (documented in the parity check); the evaluation passes
+  // -- the ones whose cost and gradient leave the kernel -- keep the stand-alone kernel's expressions.
+  const R gA = c.c_aa * q.inv_mass + c.c_tt, gB = c.c_aa * c.grav + c.c_tt * c.hov;
+  const R u1 = (R)1 - step * gA, u0 = step * gB, uP = -step * c.c_lp, uV = -step * c.c_lv;
+  const R lamP_term = c.two_wp * ((R)1 + q.term);
 #pragma unroll 1
   for (int it = 0; it < iters; ++it) {
-    R p = pinit, v = vinit;
+    R e = pinit - c.gl, v = vinit;
 #pragma unroll
     for (int k = 0; k < N; ++k) {                              // states only
       if (EXACT || k < Nn) {
-        const R acc = t[k] * q.inv_mass - c.grav;
-        es[k] = p - c.gl; vs[k] = v;
-        p = p + v * q.dt + q.half_dt2 * acc;
-        v = v + acc * q.dt;
+        const R acc = fma_r(t[k], q.inv_mass, -c.grav);
+        es[k] = e; vs[k] = v;
+        e = fma_r(q.half_dt2, acc, fma_r(v, q.dt, e));
+        v = fma_r(acc, q.dt, v);
       }
     }
     R lamP = (R)0, lamV = (R)0;
 #pragma unroll
-    for (int k = N - 1; k >= 0; --k) {                          // adjoint sweep; T_k is overwritten as soon as g_k exists
+    for (int k = N - 1; k >= 0; --k) {                          // adjoint sweep; T_k is overwritten as soon as its gradient exists
       if (EXACT || k < Nn) {
-        const R acc = t[k] * q.inv_mass - c.grav;
-        const R dev = t[k] - c.hov;
-        R g;
         if (k == Nn - 1) {
-          g = c.c_aa * acc + c.c_tt * dev;
-          lamP = c.two_wp * ((R)1 + q.term) * es[k];
+          t[k] = clamp_r(fma_r(t[k], u1, u0), lo, hi);
+          lamP = lamP_term * es[k];
           lamV = c.two_wv * vs[k];
         } else {
-          g = c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV;
-          lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
-          lamP = c.two_wp * es[k] + lamP;
+          t[k] = clamp_r(fma_r(t[k], u1, fma_r(lamP, uP, fma_r(lamV, uV, u0))), lo, hi);
+          lamV = fma_r(c.two_wv, vs[k], fma_r(q.dt, lamP, lamV));
+          lamP = fma_r(c.two_wp, es[k], lamP);
         }
-        t[k] = projected_update(t[k], g, step, lo, hi);
       }
     }
   }

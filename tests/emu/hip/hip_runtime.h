@@ -29,6 +29,8 @@
 
 using std::asin; using std::atan2; using std::fabs; using std::fmax; using std::fmin;
 using std::isinf; using std::isnan; using std::sqrt; using std::sin; using std::cos; using std::acos; using std::ldexp;
+// v_med3_f32: the median of three
+inline float __builtin_amdgcn_fmed3f(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
 
 struct dim3 {
   unsigned x, y, z;
