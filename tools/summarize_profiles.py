@@ -29,13 +29,13 @@ def durations(rows, grid_y=None):
     return dict(calls=int(len(d)), avg_ns=float(d.mean()), median_ns=float(np.median(d)), min_ns=float(d.min()), max_ns=float(d.max()))
 
 
-def counter(sub, needle, name, grid_y=None):
+def counter(sub, needle, name, grid_y=None, grid_size=None):
     f = find(sub, "*counter_collection.csv")
     if not f:
         return None
     vals = []
     for r in csv.DictReader(open(f)):
-        if needle in r["Kernel_Name"] and r["Counter_Name"] == name:
+        if needle in r["Kernel_Name"] and r["Counter_Name"] == name and (grid_size is None or int(r["Grid_Size"]) == grid_size):
             vals.append(float(r["Counter_Value"]))
     if not vals:
         return None
@@ -74,12 +74,12 @@ for tag, rollouts, gy in (("fused", 64 * B, 64), ("single", B, None), ("b4m", 41
 # ---- the on-device iteration kernel: duration per launch at K = 0 / 16 / 64 and its HBM traffic at K = 16
 it = {}
 for K in (0, 16, 64):
-    it[f"K{K}"] = durations(rows_of(f"iter_{K}", "rollout_iterate_kernel"))
+    it[f"K{K}"] = durations(rows_of(f"iter_{K}", "rollout_iterate_kernel"), 1)          # grid.y = 1: the single-batch launches
 if it.get("K0") and it.get("K16") and it.get("K64"):
     it["us_per_iteration_K16"] = (it["K16"]["avg_ns"] - it["K0"]["avg_ns"]) / 16 / 1e3
     it["us_per_iteration_K64"] = (it["K64"]["avg_ns"] - it["K0"]["avg_ns"]) / 64 / 1e3
-fe = counter("pmc_FETCH_SIZE_iter16", "rollout_iterate_kernel", "FETCH_SIZE")
-wr = counter("pmc_WRITE_SIZE_iter16", "rollout_iterate_kernel", "WRITE_SIZE")
+fe = counter("pmc_FETCH_SIZE_iter16", "rollout_iterate_kernel", "FETCH_SIZE", grid_size=192 * (B // 64))
+wr = counter("pmc_WRITE_SIZE_iter16", "rollout_iterate_kernel", "WRITE_SIZE", grid_size=192 * (B // 64))
 it["pmc_K16"] = dict(trajectories_per_launch=B, iterations=16, rollouts_per_launch=17 * B,
                      hbm_algorithmic_read_bytes=4 * (3 * N + 9) * B, hbm_algorithmic_write_bytes=4 * (6 * N + 1) * B,
                      FETCH_SIZE_KB=fe, WRITE_SIZE_KB=wr,
@@ -87,6 +87,7 @@ it["pmc_K16"] = dict(trajectories_per_launch=B, iterations=16, rollouts_per_laun
 if fe is not None and wr is not None:
     it["pmc_K16"]["traffic_bytes_per_iteration"] = (fe["mean"] * 2048 + wr["mean"] * 1024) / 17
     it["pmc_K16"]["stand_alone_launch_bytes_per_iteration"] = 4 * (6 * N + 10) * B
+it["batched_64xK16"] = durations(rows_of("iter_16", "rollout_iterate_kernel"), 64)
 out["rollout_iterate"] = it
 # ---- config legs and the closed loop
 cf = {}
