@@ -258,29 +258,44 @@ __device__ void control_step(const CtrlDev<R>& c, CtrlRegs<R>& s, double t, cons
 }
 
 // OnboardController._interpolate_trajectory (onboard.py:43-93).  ts: N timestamps (double); P, V, A: [N][3] rows (V, A may be null).
+// PlanCursor carries what one drone's clock lets the next sample reuse: the search index (np.searchsorted(ts, t) for an earlier t of the
+// same sorted plan -- the scan resumes there instead of paying up to N dependent loads per step) and the two plan rows that bracket it
+// (a loop whose simulator step is longer than the plan's, or that has run past the plan's end, samples the same rows again and again).
+template <typename R>
+struct PlanCursor {
+  int idx;          // first i with ts[i] >= t of the last sample (0 before the first)
+  int rows_of;      // idx the cached rows belong to (-1: none)
+  double t1, t2;
+  R r1[9], r2[9];   // (P, V, A) of rows idx-1 and idx (clamped)
+};
+template <typename R>
+__device__ __forceinline__ void cursor_reset(PlanCursor<R>& c) { c.idx = 0; c.rows_of = -1; }
+
 template <typename R>
 __device__ __forceinline__ void sample_plan(double t, int N, const double* __restrict__ ts, const R* __restrict__ P, const R* __restrict__ V,
-                                            const R* __restrict__ A, R tp[3], R tv[3], R ta[3], int& hint) {
-  // np.searchsorted(ts, t): first i with ts[i] >= t.  `hint` = the answer for an earlier (smaller or equal) t of the same sorted plan, 0
-  // otherwise: the closed loop's clock only moves forward, so the scan resumes where the last step stopped instead of paying up to N
-  // dependent loads per step.
-  int idx = hint;
+                                            const R* __restrict__ A, R tp[3], R tv[3], R ta[3], PlanCursor<R>& c) {
+  int idx = c.idx;                                                                // np.searchsorted(ts, t): first i with ts[i] >= t
   while (idx < N && ts[idx] < t) ++idx;
-  hint = idx;
-  int i1, i2;
-  R f = (R)0;
-  if (idx == 0) { i1 = i2 = 0; }                                                  // :51-63
-  else if (idx >= N) { i1 = i2 = N - 1; }                                         // :64-75
-  else {
-    i1 = idx - 1; i2 = idx;
-    f = (R)((t - ts[i1]) / (ts[i2] - ts[i1]));                                    // :80
+  c.idx = idx;
+  if (idx != c.rows_of) {
+    const int i1 = idx == 0 ? 0 : (idx >= N ? N - 1 : idx - 1), i2 = idx >= N ? N - 1 : idx;
+    c.t1 = ts[i1]; c.t2 = ts[i2];
+    for (int a = 0; a < 3; ++a) {
+      c.r1[a] = P[3 * i1 + a]; c.r2[a] = P[3 * i2 + a];
+      c.r1[3 + a] = V != nullptr ? V[3 * i1 + a] : (R)0; c.r2[3 + a] = V != nullptr ? V[3 * i2 + a] : (R)0;
+      c.r1[6 + a] = A != nullptr ? A[3 * i1 + a] : (R)0; c.r2[6 + a] = A != nullptr ? A[3 * i2 + a] : (R)0;
+    }
+    c.rows_of = idx;
   }
+  if (idx == 0 || idx >= N) {                                                     // :51-75: the first / last row as it stands
+    for (int a = 0; a < 3; ++a) { tp[a] = c.r1[a]; tv[a] = c.r1[3 + a]; ta[a] = c.r1[6 + a]; }
+    return;
+  }
+  const R f = (R)((t - c.t1) / (c.t2 - c.t1));                                    // :80
   for (int a = 0; a < 3; ++a) {
-    const R p1 = P[3 * i1 + a], p2 = P[3 * i2 + a];
-    tp[a] = (i1 == i2) ? p1 : p1 + f * (p2 - p1);                                 // :81
-    tv[a] = (R)0; ta[a] = (R)0;
-    if (V != nullptr) { const R v1 = V[3 * i1 + a], v2 = V[3 * i2 + a]; tv[a] = (i1 == i2) ? v1 : v1 + f * (v2 - v1); }   // :83-86
-    if (A != nullptr) { const R a1 = A[3 * i1 + a], a2 = A[3 * i2 + a]; ta[a] = (i1 == i2) ? a1 : a1 + f * (a2 - a1); }   // :88-91
+    tp[a] = c.r1[a] + f * (c.r2[a] - c.r1[a]);                                    // :81
+    tv[a] = c.r1[3 + a] + f * (c.r2[3 + a] - c.r1[3 + a]);                        // :83-86
+    ta[a] = c.r1[6 + a] + f * (c.r2[6 + a] - c.r1[6 + a]);                        // :88-91
   }
 }
 
@@ -318,9 +333,10 @@ control_kernel(CtrlDev<R> c, int B, const double* __restrict__ time, const R* __
   R p[3], v[3], a[3], w[3], dp[3], dv[3], da[3];
   for (int i = 0; i < 3; ++i) { p[i] = pos[3 * b + i]; v[i] = vel[3 * b + i]; a[i] = att[3 * b + i]; w[i] = omega[3 * b + i]; }
   if (sample_time != nullptr) {                       // compute_control_from_trajectory: the target is the plan sampled at sample_time
-    int hint = 0;
+    PlanCursor<R> cur;
+    cursor_reset(cur);
     sample_plan<R>(sample_time[b], N, timestamps + (size_t)b * ts_stride, P + (size_t)b * strideP,
-                   V != nullptr ? V + (size_t)b * strideV : nullptr, A != nullptr ? A + (size_t)b * strideA : nullptr, dp, dv, da, hint);
+                   V != nullptr ? V + (size_t)b * strideV : nullptr, A != nullptr ? A + (size_t)b * strideA : nullptr, dp, dv, da, cur);
     if (target != nullptr) for (int i = 0; i < 3; ++i) { target[9 * b + i] = dp[i]; target[9 * b + 3 + i] = dv[i]; target[9 * b + 6 + i] = da[i]; }
   } else {
     for (int i = 0; i < 3; ++i) { dp[i] = dpos[3 * b + i]; dv[i] = dvel[3 * b + i]; da[i] = dacc != nullptr ? dacc[3 * b + i] : (R)0; }
@@ -363,8 +379,10 @@ closed_loop_kernel(CtrlDev<R> c, SimDev<R> m, int B, int nsteps, double sim_dt, 
   const R* Ab = A != nullptr ? A + (size_t)b * strideA : nullptr;
   const double ts_last = ts[N - 1];
   const R dt = (R)sim_dt;
-  int taken = 0, hint = 0;
+  int taken = 0;
   bool active = true;
+  PlanCursor<R> cur;
+  cursor_reset(cur);
   for (int step = 0; step < nsteps; ++step) {
     if (stop_at_plan_end && t > ts_last) active = false;                          // contract tests :130-131 / :263-264 (`break`)
     if (log_state != nullptr) {
@@ -375,8 +393,8 @@ closed_loop_kernel(CtrlDev<R> c, SimDev<R> m, int B, int nsteps, double sim_dt, 
     R th = (R)NAN, tq[3] = {(R)NAN, (R)NAN, (R)NAN};
     if (active) {
       R tp[3], tv[3], ta[3];
-      if (!(sim_dt > 0.0)) hint = 0;                                           // a clock that does not advance: search from the start
-      sample_plan<R>(t, N, ts, Pb, Vb, Ab, tp, tv, ta, hint);
+      if (!(sim_dt > 0.0)) cur.idx = 0;                                        // a clock that does not advance: search from the start
+      sample_plan<R>(t, N, ts, Pb, Vb, Ab, tp, tv, ta, cur);
       int fl;
       control_step<R>(c, s, t, p, v, a, w, tp, tv, ta, (R)0, (R)0, th, tq, fl);
       if (step == gust_step) { wd[0] = gx; wd[1] = gy; wd[2] = gz; }              // the gust of contract test :293-296
