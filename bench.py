@@ -206,7 +206,9 @@ def capture(torch, dev, fn):
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, stream=side):
+        # thread_local: with N > 1 ranks RCCL's watchdog thread issues event queries of its own; under the default (global)
+        # capture mode any such call from another thread would invalidate the capture
+        with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
             fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()

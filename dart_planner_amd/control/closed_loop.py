@@ -60,7 +60,7 @@ class ClosedLoopMonteCarlo:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 out = run()
         torch.cuda.current_stream().wait_stream(side)
 

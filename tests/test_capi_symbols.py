@@ -44,6 +44,19 @@ def test_library_loads_through_the_binding_without_a_gpu(lib_path):
     assert lib.check_params(capi.Params.reference_defaults(horizon=65)) == -2
     assert lib.device_count() >= 0          # 0 on a CPU-only box; must not crash
     assert ctypes.sizeof(capi.Params) == 160 and ctypes.sizeof(capi.SolveInfo) == 24 and ctypes.sizeof(capi.VoxelMapDesc) == 48
+    assert ctypes.sizeof(capi.ControllerParams) == 304 and ctypes.sizeof(capi.SimulatorParams) == 56      # static_asserts in csrc/closed_loop.hip
+    assert bytes(lib.controller_default_params()) == bytes(capi.ControllerParams.from_config(_ReferenceControllerDefaults()))
+
+
+class _ReferenceControllerDefaults:
+    """GeometricControllerConfig after the "sitl_optimized" profile, as the reference instantiates it (tests/golden/controller_cases.json)."""
+    kp_pos, ki_pos, kd_pos = (20.0, 20.0, 25.0), (1.5, 1.5, 2.0), (10.0, 10.0, 12.0)
+    kp_att, kd_att = (18.0, 18.0, 8.0), (7.0, 7.0, 3.5)
+    inertia, max_torque_xyz, max_integral_per_axis = (0.02, 0.02, 0.04), (0.5, 0.5, 0.05), (2.0, 2.0, 3.0)
+    max_integral_pos, max_tilt_angle, mass, gravity, max_thrust, min_thrust = 2.5, 0.7853981633974483, 1.0, 9.80665, 22.0, 0.8
+    tracking_error_threshold, velocity_error_threshold = 1.0, 0.6
+    back_calculation_gain, integral_decay_factor, saturation_threshold, yaw_singularity_threshold, default_heading_yaw = 0.1, 0.99, 0.95, 0.1, 0.0
+    anti_windup_method, yaw_singularity_fallback_method = "clamping", "skip_yaw"
 
 
 def test_missing_library_fails_loudly(tmp_path):
