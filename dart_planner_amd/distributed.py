@@ -127,3 +127,48 @@ def sharded_restart_solve(ops, params, p0, v0, goal, n_restarts: int, sigma: flo
     if dist_on:
         dist.broadcast(xw, src=owner)
     return dict(x=xw.to(torch.float64).cpu().numpy(), cost=ops.lib.key_cost(kh), restart=win, owner=owner)
+
+
+def sharded_shooting_plan(ops, params, p0, v0, goal, n_samples: int, iters: int = 16, step: float = 0.9, sigma: float = 2.0, seed: int = 0,
+                          precision: str = "f32") -> Dict[str, np.ndarray]:
+    """One problem, `n_samples` thrust sequences sharded over the ranks of the default process group -- the north_star's "sample batch
+    shards across the GPUs with a single all-reduce for the argmin" on the shooting form: every rank draws its samples (sample 0 = hover
+    thrust, sample s > 0 = hover + N(0, sigma) newtons from a generator seeded by (seed, s), so the result does not depend on the number
+    of ranks), descends each of them `iters` projected-gradient iterations in ONE launch (se3mpc_rollout_iterate_*, thrust sequences in
+    registers), folds the fused per-wavefront argmin keys, ONE all-reduce(MIN) of the 8-byte key, and the owner broadcasts the winning
+    thrust sequence (3N values).  Returns on every rank: T (N, 3), its cost, the winning sample and its owner."""
+    import torch
+    import torch.distributed as dist
+    dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    rank = dist.get_rank() if dist_on else 0
+    world = dist.get_world_size() if dist_on else 1
+    dev = ops.be.device
+    dt = torch.float32 if precision == "f32" else torch.float64
+    N = params.horizon
+    lo, hi = shard_bounds(n_samples, rank, world)
+    R = hi - lo
+    best = torch.full((1,), -1, dtype=torch.int64, device=dev)
+    Tout = None
+    if R > 0:
+        hover = params.mass * params.gravity
+        T = np.zeros((R, N, 3))
+        T[:, :, 2] = hover
+        for i, s_ in enumerate(range(lo, hi)):
+            if s_ > 0:
+                T[i] += np.random.default_rng([seed, s_]).normal(0.0, sigma, (N, 3))
+        col = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(np.asarray(a, float).reshape(3, 1), (1, R)))).to(device=dev, dtype=dt)
+        lane = torch.from_numpy(np.ascontiguousarray(T.reshape(R, 3 * N).T)).to(device=dev, dtype=dt)
+        wk = torch.zeros(((R + 63) // 64,), dtype=torch.int64, device=dev)
+        out = ops.rollout_iterate(params, col(p0), col(v0), col(goal), lane, int(iters), float(step), want_grad=False, wave_keys=wk, index_base=lo)
+        Tout = out["T"]
+        ops.reduce_keys(wk.view(1, -1), best)
+    allreduce_min_keys(best)
+    kh = int(best.cpu().numpy()[0]) & 0xFFFFFFFFFFFFFFFF
+    win = ops.lib.key_index(kh)
+    owner = next(r for r in range(world) if shard_bounds(n_samples, r, world)[0] <= win < shard_bounds(n_samples, r, world)[1])
+    tw = torch.zeros(3 * N, dtype=dt, device=dev)
+    if rank == owner:
+        tw.copy_(Tout[:, win - lo])
+    if dist_on:
+        dist.broadcast(tw, src=owner)
+    return dict(T=tw.to(torch.float64).cpu().numpy().reshape(N, 3), cost=ops.lib.key_cost(kh), sample=win, owner=owner)

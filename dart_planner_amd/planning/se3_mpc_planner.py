@@ -290,6 +290,35 @@ class SE3MPCPlanner(BasePlanner):
                                          "body_rates", "thrusts")}
         return self._create_trajectory_from_solution(sol, time.time())
 
+    def plan_shooting(self, current_state: DroneState, goal_position, n_samples: int = 8192, iters: int = 16, step: float = 0.9,
+                      sigma: float = 2.0, seed: int = 0, precision: str = "f32") -> Trajectory:
+        """The shooting-form counterpart of :meth:`plan_trajectory` (the build's construct, like the restarts): `n_samples` thrust
+        sequences around hover are each descended `iters` projected-gradient iterations on the device (ONE launch,
+        ``se3mpc_rollout_iterate_*``; with several ranks the samples shard and one all-reduce(MIN) picks the winner,
+        ``distributed.sharded_shooting_plan``), the best one is rolled out (``se3mpc_rollout_cost_grad_*`` with states) and its
+        accelerations / attitudes / body rates / thrust magnitudes extracted (``se3mpc_extract_*``).  Unlike the reference's solve, whose
+        dynamics constraints never reach the optimiser, this plan satisfies the dynamics by construction."""
+        import torch
+        from ..distributed import sharded_shooting_plan
+        current_state, _, _ = self.sense(current_state, goal_position)
+        ops = self._get_ops()
+        prm = self._params()
+        N = self.se3_config.prediction_horizon
+        p0 = np.asarray(to_float(current_state.position), float)
+        v0 = np.asarray(to_float(current_state.velocity), float)
+        best = sharded_shooting_plan(ops, prm, p0, v0, self.goal_position, n_samples, iters, step, sigma, seed, precision)
+        dev = ops.be.device
+        col = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, float).reshape(-1, 1))).to(dev)
+        T = col(best["T"].reshape(-1))
+        cost, _, P, V = ops.rollout_cost_grad(prm, col(p0), col(v0), col(self.goal_position), T, want_grad=False, want_states=True)
+        acc, att, rates, thr = ops.extract(prm, T)
+        h = lambda a, shape: ops.be.to_host(a)[:, 0].reshape(shape).astype(float)
+        self.last_result = dict(cost=float(ops.be.to_host(cost)[0]), sample=int(best["sample"]), owner=int(best["owner"]), n_samples=int(n_samples),
+                                iters=int(iters))
+        sol = {"positions": h(P, (N, 3)), "velocities": h(V, (N, 3)), "thrust_vectors": best["T"], "accelerations": h(acc, (N, 3)),
+               "attitudes": h(att, (N, 3)), "body_rates": h(rates, (N, 3)), "thrusts": h(thr, (N,))}
+        return self._create_trajectory_from_solution(sol, time.time())
+
     def _create_warm_start(self, current_state: DroneState, N: int) -> np.ndarray:
         """planner.py:294-327: shift the previous solution by one step, re-anchor step 0 at the current
         state, extend to the goal with hover thrust."""

@@ -45,11 +45,14 @@ def _worker(rank, world, port, q):
     ops.argmin(cs, index_base=lo, out=kmin)
     D.allreduce_min_keys(kmin)
     mean = D.allreduce_population_mean(ops.population_sums(Xs, cost=cs, temperature=POP_TEMPERATURE, ref_key=kmin))
-    q.put((rank, res["restart"], res["owner"], res["cost"], res["x"], keys.numpy().view(np.uint64).tolist(), mean.numpy()))
+    shoot = D.sharded_shooting_plan(_ops(), Params.reference_defaults(horizon=6), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"], n_samples=SHOOT_SAMPLES,
+                                    iters=3, step=0.9, sigma=4.0, seed=8, precision="f64")
+    q.put((rank, res["restart"], res["owner"], res["cost"], res["x"], keys.numpy().view(np.uint64).tolist(), mean.numpy(), shoot))
     torch.distributed.destroy_process_group()
 
 
 POP_TEMPERATURE = 3.0
+SHOOT_SAMPLES = 131
 
 
 def _population():
@@ -85,7 +88,12 @@ def test_two_rank_restart_argmin_matches_single_process():
     Xall, call = _population()
     w = np.exp(-(call.astype(np.float64) - float(call.min())) / POP_TEMPERATURE)
     mean_ref = (Xall.astype(np.float64) * w).sum(1) / w.sum()
-    for rank, restart, owner, cost, x, keys, mean in got:
+    shoot1 = D.sharded_shooting_plan(_ops(), Params.reference_defaults(horizon=6), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"], n_samples=SHOOT_SAMPLES,
+                                     iters=3, step=0.9, sigma=4.0, seed=8, precision="f64")
+    for rank, restart, owner, cost, x, keys, mean, shoot in got:
+        # the sharded shooting plan (samples over two ranks, one key all-reduce, winner broadcast) == all samples in one process
+        assert shoot["sample"] == shoot1["sample"] and shoot["cost"] == shoot1["cost"] and np.array_equal(shoot["T"], shoot1["T"])
+        assert shoot["owner"] == (0 if shoot["sample"] < 66 else 1)
         assert np.allclose(mean, mean_ref, rtol=1e-12, atol=1e-14)
         assert restart == single["restart"] and cost == single["cost"]
         assert np.array_equal(x, single["x"])

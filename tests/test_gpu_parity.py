@@ -406,3 +406,35 @@ def test_wave_ops_selftest(gpu_ops):
         key = torch.full((1,), -1, dtype=torch.int64, device=dev)
         cost, *_ = ops.rollout_cost_grad(prm, p0, v0, goal, T, want_grad=False, key=key)
         assert ops.decode_key(key)[0] == pos == int(torch.argmin(cost))
+
+
+def test_planner_shooting_plan(gpu_ops):
+    """SE3MPCPlanner.plan_shooting: 8192 thrust samples x 16 iterations in one launch, argmin, rollout and extraction of the winner.  The
+    winner's thrust sequence is what the host-chained oracle produces from the same sample, the Trajectory satisfies the reference's dynamics
+    constraints (the rollout is their zero set), and it is at least as cheap as the hover sample after the same iterations."""
+    from dart_planner_amd.common.types import DroneState
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCConfig, SE3MPCPlanner
+    N, S, K = 30, 8192, 16
+    pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N), precision="f64")
+    st = DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.array([0.5, -0.2, 0.1]))
+    goal = np.array([5.0, 3.0, 2.0])
+    tr = pl.plan_shooting(st, goal, n_samples=S, iters=K, step=0.9, sigma=2.0, seed=3, precision="f32")
+    assert tr.positions.shape == (N, 3) and tr.thrusts.shape == (N,) and np.all(tr.thrusts > 0)
+    assert np.allclose(tr.positions[0], st.position) and np.allclose(tr.velocities[0], st.velocity)
+    s_win = pl.last_result["sample"]
+    cfg = orc.OracleConfig(prediction_horizon=N)
+    T0 = np.zeros((1, N, 3)); T0[:, :, 2] = cfg.hover_thrust
+    if s_win > 0:
+        T0 += np.random.default_rng([3, s_win]).normal(0.0, 2.0, (N, 3))
+    f32 = lambda a: np.asarray(a, np.float32).astype(float)
+    Tr, cr, _, _ = pc.oracle_iterate(f32(st.position)[None], f32(st.velocity)[None], f32(goal)[None], f32(T0), cfg, K, 0.9)
+    Tw = np.asarray(tr.accelerations) * cfg.mass + [0, 0, cfg.mass * cfg.gravity]                # accelerations = T/m - g e3
+    assert np.max(np.abs(Tw - Tr[0])) <= 2e-4
+    assert abs(pl.last_result["cost"] - cr[0]) <= 5e-5 * cr[0]
+    # the hover sample after the same iterations costs at least as much
+    Th, ch, _, _ = pc.oracle_iterate(f32(st.position)[None], f32(st.velocity)[None], f32(goal)[None], np.tile([0, 0, cfg.hover_thrust], (1, N, 1)), cfg, K, 0.9)
+    assert pl.last_result["cost"] <= ch[0] * (1 + 1e-5)
+    # dynamics constraints of the reference (planner.py:426-462) on the returned plan: zero
+    X = orc.pack(np.asarray(tr.positions)[None], np.asarray(tr.velocities)[None], Tw[None])
+    R = orc.dynamics_residual(X, st.position[None], st.velocity[None], cfg)
+    assert np.max(np.abs(R)) <= 1e-9
