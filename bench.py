@@ -511,6 +511,18 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
                 ts.append((time.perf_counter() - t0) * 1e3)
         out[f"single_{prec}"] = {"horizon": N, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
                                  "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(np.max(ts))}
+    # the shooting-form plan through the same mirror: 8192 thrust samples x 16 iterations in one launch, argmin, rollout + extraction of the winner
+    if world == 1:
+        pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N), precision="f64", device=dev)
+        ts = []
+        for i, g in enumerate(goals[:120]):
+            t0 = time.perf_counter()
+            pl.plan_shooting(st, g, n_samples=B, iters=16, seed=i)
+            torch.cuda.synchronize()
+            if i >= 20:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        out["shooting_plan_f32"] = {"horizon": N, "samples": B, "iterations": 16, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
+                                    "p95_ms": float(np.percentile(ts, 95)), "rollouts_per_plan": B * 17}
     prm = Params.reference_defaults(horizon=N)
     g = torch.Generator(device=dev); g.manual_seed(100 + rank)
     p0 = torch.rand(B, 3, device=dev, generator=g) * 40 - 20

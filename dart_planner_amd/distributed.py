@@ -129,12 +129,25 @@ def sharded_restart_solve(ops, params, p0, v0, goal, n_restarts: int, sigma: flo
     return dict(x=xw.to(torch.float64).cpu().numpy(), cost=ops.lib.key_cost(kh), restart=win, owner=owner)
 
 
+def shooting_samples(params, n_samples: int, sigma: float, seed: int, device, dtype):
+    """The thrust samples of :func:`sharded_shooting_plan` in lane layout (3N, n_samples): sample 0 = hover thrust, sample s > 0 = hover +
+    N(0, sigma) newtons.  Drawn on the device from ONE generator seeded with `seed`; every rank draws the whole set and keeps its shard, so the
+    samples -- and the winner -- do not depend on the number of ranks."""
+    import torch
+    N = params.horizon
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    T = torch.randn(3 * N, n_samples, generator=g, device=device, dtype=dtype) * float(sigma)
+    T[:, 0] = 0.0
+    T[2::3] += params.mass * params.gravity
+    return T
+
+
 def sharded_shooting_plan(ops, params, p0, v0, goal, n_samples: int, iters: int = 16, step: float = 0.9, sigma: float = 2.0, seed: int = 0,
                           precision: str = "f32") -> Dict[str, np.ndarray]:
     """One problem, `n_samples` thrust sequences sharded over the ranks of the default process group -- the north_star's "sample batch
     shards across the GPUs with a single all-reduce for the argmin" on the shooting form: every rank draws its samples (sample 0 = hover
-    thrust, sample s > 0 = hover + N(0, sigma) newtons from a generator seeded by (seed, s), so the result does not depend on the number
-    of ranks), descends each of them `iters` projected-gradient iterations in ONE launch (se3mpc_rollout_iterate_*, thrust sequences in
+    thrust, sample s > 0 = hover + N(0, sigma) newtons; :func:`shooting_samples`: the result does not depend on the number of ranks), descends each of them `iters` projected-gradient iterations in ONE launch (se3mpc_rollout_iterate_*, thrust sequences in
     registers), folds the fused per-wavefront argmin keys, ONE all-reduce(MIN) of the 8-byte key, and the owner broadcasts the winning
     thrust sequence (3N values).  Returns on every rank: T (N, 3), its cost, the winning sample and its owner."""
     import torch
@@ -150,14 +163,8 @@ def sharded_shooting_plan(ops, params, p0, v0, goal, n_samples: int, iters: int 
     best = torch.full((1,), -1, dtype=torch.int64, device=dev)
     Tout = None
     if R > 0:
-        hover = params.mass * params.gravity
-        T = np.zeros((R, N, 3))
-        T[:, :, 2] = hover
-        for i, s_ in enumerate(range(lo, hi)):
-            if s_ > 0:
-                T[i] += np.random.default_rng([seed, s_]).normal(0.0, sigma, (N, 3))
+        lane = shooting_samples(params, n_samples, sigma, seed, dev, dt)[:, lo:hi].contiguous()
         col = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(np.asarray(a, float).reshape(3, 1), (1, R)))).to(device=dev, dtype=dt)
-        lane = torch.from_numpy(np.ascontiguousarray(T.reshape(R, 3 * N).T)).to(device=dev, dtype=dt)
         wk = torch.zeros(((R + 63) // 64,), dtype=torch.int64, device=dev)
         out = ops.rollout_iterate(params, col(p0), col(v0), col(goal), lane, int(iters), float(step), want_grad=False, wave_keys=wk, index_base=lo)
         Tout = out["T"]

@@ -423,9 +423,9 @@ def test_planner_shooting_plan(gpu_ops):
     assert np.allclose(tr.positions[0], st.position) and np.allclose(tr.velocities[0], st.velocity)
     s_win = pl.last_result["sample"]
     cfg = orc.OracleConfig(prediction_horizon=N)
-    T0 = np.zeros((1, N, 3)); T0[:, :, 2] = cfg.hover_thrust
-    if s_win > 0:
-        T0 += np.random.default_rng([3, s_win]).normal(0.0, 2.0, (N, 3))
+    import torch
+    from dart_planner_amd.distributed import shooting_samples
+    T0 = shooting_samples(pl._params(), S, 2.0, 3, gpu_ops.be.device, torch.float32)[:, s_win].double().cpu().numpy().reshape(1, N, 3)
     f32 = lambda a: np.asarray(a, np.float32).astype(float)
     Tr, cr, _, _ = pc.oracle_iterate(f32(st.position)[None], f32(st.velocity)[None], f32(goal)[None], f32(T0), cfg, K, 0.9)
     Tw = np.asarray(tr.accelerations) * cfg.mass + [0, 0, cfg.mass * cfg.gravity]                # accelerations = T/m - g e3
