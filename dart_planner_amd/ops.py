@@ -71,6 +71,11 @@ class TorchBackend:
     def from_host(self, a: np.ndarray):
         return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.device)
 
+    def elements_from(self, a) -> int:
+        """How many elements of a's dtype lie between a's first element and the end of its storage (views into a larger tensor reach
+        past their own numel): what a kernel that strides from a.data_ptr() may legally touch."""
+        return (a.untyped_storage().nbytes() - a.storage_offset() * a.element_size()) // a.element_size()
+
 
 class Ops:
     """Shape-checked calls into libse3mpc for one array backend."""
@@ -461,6 +466,10 @@ class Ops:
             sP, sV, sA = st_of(P, "P"), st_of(V, "V"), st_of(A, "A")
         else:
             sP, sV, sA = (int(x) for x in strides)
+            if hasattr(self.be, "elements_from"):              # explicit strides read past the views' own shapes: check the storage instead
+                for a, st, nm in ((P, sP, "P"), (V, sV, "V"), (A, sA, "A")):
+                    if a is not None and (st < 0 or (B - 1) * st + 3 * N > self.be.elements_from(a)):
+                        raise ValueError(f"{nm}: stride {st} x {B} plans of {N} rows runs past the tensor's storage")
         return N, ts_stride, sP, sV, sA
 
     def control_plan(self, cp: ControllerParams, state, time, sample_time, pos, vel, att, omega, timestamps, P, V=None, A=None,

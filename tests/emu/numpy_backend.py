@@ -70,5 +70,8 @@ class TorchCpuBackend:
     def to_host(self, a):
         return a.numpy()
 
+    def elements_from(self, a):
+        return (a.untyped_storage().nbytes() - a.storage_offset() * a.element_size()) // a.element_size()
+
     def from_host(self, a):
         return self.torch.from_numpy(np.ascontiguousarray(a).copy())

@@ -263,3 +263,25 @@ def test_monte_carlo_hipgraph_replay_equals_eager(gpu_ops):
         torch.cuda.synchronize()
         for k in ("pos", "vel", "att", "omega", "time", "controller_state"):
             assert torch.equal(out[k], eager[k]), (trial, k)
+
+
+def test_closed_loop_refuses_strides_that_leave_the_storage(gpu_ops):
+    """Explicit plan strides read past the views' shapes; a stride that would run off the tensor's storage is refused on the host, before any
+    launch (an out-of-bounds read on the device can take the whole node down)."""
+    import torch
+    from dart_planner_amd.capi import ControllerParams, SimulatorParams
+    ops = gpu_ops
+    dev = ops.be.device
+    cp, sp = ControllerParams.from_config(co.ControllerConfig()), SimulatorParams.reference_defaults()
+    B, N = 8, 6
+    X = torch.zeros(B, 9 * N, dtype=torch.float64, device=dev)
+    acc = torch.zeros(B, N, 3, dtype=torch.float64, device=dev)
+    z = torch.zeros(B, 3, dtype=torch.float64, device=dev)
+    t = torch.zeros(B, dtype=torch.float64, device=dev)
+    ts = torch.arange(N, dtype=torch.float64, device=dev) / 400
+    st = ops.controller_state(cp, B)
+    ops.closed_loop(cp, sp, st, t, z.clone(), z.clone(), z.clone(), z.clone(), ts, X, X[:, 3 * N:], acc, nsteps=2, strides=(9 * N, 9 * N, 3 * N))   # legal
+    with pytest.raises(ValueError, match="storage"):
+        ops.closed_loop(cp, sp, st, t, z.clone(), z.clone(), z.clone(), z.clone(), ts, X, X[:, 3 * N:], acc, nsteps=2, strides=(9 * N, 9 * N, 9 * N))  # acc is 3N wide
+    with pytest.raises(ValueError, match="storage"):
+        ops.closed_loop(cp, sp, st, t, z.clone(), z.clone(), z.clone(), z.clone(), ts, X[:4], X[:, 3 * N:], acc, nsteps=2, strides=(19 * N, 9 * N, 3 * N))
