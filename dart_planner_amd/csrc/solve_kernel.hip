@@ -7,8 +7,10 @@
 // implementation of the published algorithm (Byrd-Lu-Nocedal-Zhu 1995; Morales-Nocedal 2011;
 // More-Thuente line search), structured like oracle/lbfgsb_port.py which is pinned to SciPy.
 //
-// Mapping.  n = 9N <= 576 decision variables; lane L owns elements i = L + 64 j, j < J
-// (J = ceil(n/64) is a template parameter, so x, g, d, z, x_old, g_old live in registers).  Dot
+// Mapping.  n = 9N <= 576 decision variables; lane L owns J = 3*ceil(3N/64) register slots, slot j =
+// element L + 64 (j mod JB) of block j / JB (positions, velocities, thrusts: "slot layout" below;
+// J is a template parameter, so x, g, d, z, x_old, g_old live in registers and every slot's objective
+// term and box are fixed at compile time).  Dot
 // products / norms / argmins are per-lane partials + a DPP wavefront reduction (no LDS).  The
 // L-BFGS pairs S, Y (m x n) live in LDS, each lane touching only its own elements (bank = lane:
 // conflict free).  The m x m / 2m x 2m middle matrices and their Cholesky / triangular solves
@@ -31,7 +33,7 @@
 #endif
 
 #ifndef SE3MPC_SOLVE_WAVES
-#define SE3MPC_SOLVE_WAVES 2      // resident wavefronts per SIMD the register allocation leaves room for (J <= 5); 3 was measured slower (spills)
+#define SE3MPC_SOLVE_WAVES 2      // resident wavefronts per SIMD the register allocation leaves room for (J <= 6); 3 was measured slower (spills)
 #endif
 
 namespace se3mpc {
@@ -61,23 +63,28 @@ static SolveDev make_solve_dev(const se3mpc_params& p) {
   return d;
 }
 
+// Slot layout.  A lane keeps J = 3*JB elements in registers, JB = ceil(3N / 64) slots per block of the decision vector: slot j holds element
+// r = lane + 64*(j % JB) of block j / JB (0 positions, 1 velocities, 2 thrusts), i.e. decision-vector element (j / JB)*3N + r.  Every slot is
+// block-uniform, so which objective term and which box a slot needs is known when the J-loops are unrolled; only the axis (r % 3), the terminal
+// position row and the padding (r >= 3N, possible in the last slot of a block only) differ between lanes.
 // per-element code: bits 0-1 block (0 P, 1 V, 2 T, 3 padding), bits 2-3 axis, bit 4 terminal P row
-__device__ __forceinline__ int elem_code(const SolveDev& q, int i) {
-  if (i >= q.n) return 3;
-  const int n3 = 3 * q.N;
-  const int blk = i / n3, r = i - blk * n3, k = r / 3, a = r - 3 * k;
+__device__ __forceinline__ int slot_code(const SolveDev& q, int blk, int r) {
+  if (r >= 3 * q.N) return 3;
+  const int k = r / 3, a = r - 3 * k;
   return blk | (a << 2) | ((blk == 0 && k == q.N - 1) ? 16 : 0);
 }
-__device__ __forceinline__ void elem_bounds(const SolveDev& q, int code, double& lo, double& hi) {
-  const int blk = code & 3, a = (code >> 2) & 3;
+template <int J>
+__device__ __forceinline__ void slot_bounds(const SolveDev& q, int j, int code, double& lo, double& hi) {
+  constexpr int JB = J / 3;
+  const int blk = j / JB;
   if (blk == 0) { lo = -q.pos_b; hi = q.pos_b; }
   else if (blk == 1) { lo = -q.v_max; hi = q.v_max; }
-  else if (blk == 2) { if (a == 2) { lo = q.tz_lo; hi = q.tz_hi; } else { lo = -q.txy; hi = q.txy; } }
-  else { lo = 0.0; hi = 0.0; }
+  else { const bool zax = ((code >> 2) & 3) == 2; lo = zax ? q.tz_lo : -q.txy; hi = zax ? q.tz_hi : q.txy; }
+  if (j % JB == JB - 1 && (code & 3) == 3) { lo = 0.0; hi = 0.0; }
 }
 
 // Moré-Thuente safeguarded step (MINPACK-2 dcstep).
-__device__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
+__device__ __forceinline__ void dcstep(double& stx, double& fx, double& dx, double& sty, double& fy, double& dy, double& stp,
                        double fp, double dp, bool& brackt, double stpmin, double stpmax) {
   const double sgnd = dp * (dx / fabs(dx));
   double stpf;
@@ -132,11 +139,13 @@ __device__ void dcstep(double& stx, double& fx, double& dx, double& sty, double&
     } else if (stp > stx) stpf = stpmax;
     else stpf = stpmin;
   }
-  if (fp > fx) { sty = stp; fy = fp; dy = dp; }
-  else {
-    if (sgnd < 0.0) { sty = stx; fy = fx; dy = dx; }
-    stx = stp; fx = fp; dx = dp;
-  }
+  // interval update, written as value selects (as `if (..) {sty = ..} else {stx = ..}` the compiler stores through a selected pointer,
+  // which puts fx, dx, fy, dy into scratch memory)
+  const bool up = fp > fx, swap = !up && sgnd < 0.0;
+  const double nsty = up ? stp : (swap ? stx : sty), nfy = up ? fp : (swap ? fx : fy), ndy = up ? dp : (swap ? dx : dy);
+  const double nstx = up ? stx : stp, nfx = up ? fx : fp, ndx = up ? dx : dp;
+  sty = nsty; fy = nfy; dy = ndy;
+  stx = nstx; fx = nfx; dx = ndx;
   stp = stpf;
 }
 
@@ -147,7 +156,7 @@ struct LineSearch {
 };
 enum { LS_FG = 0, LS_CONV = 1, LS_WARN = 2, LS_ERROR = 3 };
 
-__device__ int dcsrch(double f, double g, double& stp, double stpmin, double stpmax, bool start, LineSearch& s) {
+__device__ __forceinline__ int dcsrch(double f, double g, double& stp, double stpmin, double stpmax, bool start, LineSearch& s) {
   const double ftol = 1.0e-3, gtol = 0.9, xtol = 0.1, xtrapl = 1.1, xtrapu = 4.0, p5 = 0.5, p66 = 0.66;
   if (start) {
     if (stp < stpmin || stp > stpmax || g >= 0.0 || stpmax < stpmin) return LS_ERROR;
@@ -166,17 +175,22 @@ __device__ int dcsrch(double f, double g, double& stp, double stpmin, double stp
   if (stp == stpmin && (f > ftest || g >= s.gtest)) task = LS_WARN;
   if (f <= ftest && fabs(g) <= gtol * (-s.ginit)) task = LS_CONV;
   if (task != LS_FG) return task;
-  if (s.stage == 1 && f <= s.fx && f > ftest) {
-    const double fm = f - stp * s.gtest;
-    double fxm = s.fx - s.stx * s.gtest, fym = s.fy - s.sty * s.gtest;
-    const double gm = g - s.gtest;
-    double gxm = s.gx - s.gtest, gym = s.gy - s.gtest;
-    dcstep(s.stx, fxm, gxm, s.sty, fym, gym, stp, fm, gm, s.brackt, s.stmin, s.stmax);
-    s.fx = fxm + s.stx * s.gtest; s.fy = fym + s.sty * s.gtest;
-    s.gx = gxm + s.gtest; s.gy = gym + s.gtest;
-  } else {
-    dcstep(s.stx, s.fx, s.gx, s.sty, s.fy, s.gy, stp, f, g, s.brackt, s.stmin, s.stmax);
+  // ONE dcstep call on local copies (the modified function of stage 1 or the function itself): handing dcstep either locals or the
+  // members by reference made the compiler keep fx, gx, fy, gy in scratch memory behind a selected pointer.
+  const bool modified = s.stage == 1 && f <= s.fx && f > ftest;
+  double fxv = s.fx, gxv = s.gx, fyv = s.fy, gyv = s.gy, fv = f, gv = g;
+  if (modified) {
+    fv = f - stp * s.gtest;
+    fxv = s.fx - s.stx * s.gtest; fyv = s.fy - s.sty * s.gtest;
+    gv = g - s.gtest;
+    gxv = s.gx - s.gtest; gyv = s.gy - s.gtest;
   }
+  dcstep(s.stx, fxv, gxv, s.sty, fyv, gyv, stp, fv, gv, s.brackt, s.stmin, s.stmax);
+  if (modified) {
+    fxv = fxv + s.stx * s.gtest; fyv = fyv + s.sty * s.gtest;
+    gxv = gxv + s.gtest; gyv = gyv + s.gtest;
+  }
+  s.fx = fxv; s.gx = gxv; s.fy = fyv; s.gy = gyv;
   if (s.brackt) {
     if (fabs(s.sty - s.stx) >= p66 * s.width1) stp = s.stx + p5 * (s.sty - s.stx);
     s.width1 = s.width; s.width = fabs(s.sty - s.stx);
@@ -353,10 +367,11 @@ __device__ __forceinline__ int dtrsl_regs(const double (&t)[N][N], double (&b)[N
   if (!transposed) {
     b[N - 1] = b[N - 1] / t[N - 1][N - 1];
 #pragma unroll
-    for (int j = N - 2; j >= 0; --j) {
+    for (int jr = 0; jr < N - 1; ++jr) {                      // j = N-2 .. 0 (counted upwards: the descending form is left rolled, and b[] in scratch)
+      const int j = N - 2 - jr;
       const double temp = -b[j + 1];
 #pragma unroll
-      for (int i = 0; i <= j; ++i) b[i] += temp * t[i][j + 1];
+      for (int i = 0; i < N; ++i) if (i <= j) b[i] += temp * t[i][j + 1];
       b[j] = b[j] / t[j][j];
     }
   } else {
@@ -409,7 +424,7 @@ struct ColTag { static constexpr int value = C; };
 // 2nd launch-bounds argument = wavefronts per SIMD the register allocation must leave room for: two
 // resident solves per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
 template <typename IO, int J>
-__global__ void __launch_bounds__(64, (J <= 5 ? SE3MPC_SOLVE_WAVES : 1))
+__global__ void __launch_bounds__(64, (J <= 6 ? SE3MPC_SOLVE_WAVES : 1))
 solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict__ v0g, const IO* __restrict__ goalg,
              const IO* __restrict__ x0g, IO* __restrict__ Xg, se3mpc_solve_info* __restrict__ infog,
              IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg) {
@@ -459,25 +474,27 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   const unsigned long long tstart = tlast;
 #endif
   // ---- cold start (planner.py:329-359) or caller x0, projected into the box (L-BFGS-B `active`)
+  constexpr int JB = J / 3;
+  const int n3 = 3 * N;
   double xw[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int i = lane + kWave * j;
-    xw[j] = (!cold && i < n) ? (double)x0g[(size_t)pb * n + i] : 0.0;
+    const int r = lane + kWave * (j % JB);
+    xw[j] = (!cold && r < n3) ? (double)x0g[(size_t)pb * n + (j / JB) * n3 + r] : 0.0;
   }
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int i = lane + kWave * j;
-    code[j] = elem_code(q, i);
+    const int blk = j / JB, r = lane + kWave * (j % JB);
+    code[j] = slot_code(q, blk, r);
     double lo, hi;
-    elem_bounds(q, code[j], lo, hi);
+    slot_bounds<J>(q, j, code[j], lo, hi);
     double xv = 0.0;
-    const int blk = code[j] & 3, a = (code[j] >> 2) & 3;
-    if (blk != 3) {
+    const int a = (code[j] >> 2) & 3;
+    if ((code[j] & 3) != 3) {
       if (!cold) {
         xv = xw[j];
       } else {
-        const int r = i - blk * 3 * N, k = r / 3;
+        const int k = r / 3;
         const double pa = a == 0 ? ps0 : (a == 1 ? ps1 : ps2), va = a == 0 ? vs0 : (a == 1 ? vs1 : vs2), ga = goal_of(code[j]);
         const double denom = (double)(N - 1 > 1 ? N - 1 : 1);
         if (blk == 0) {
@@ -516,7 +533,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     double part = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      const int blk = code[j] & 3, a = (code[j] >> 2) & 3;
+      const int blk = j / JB, a = (code[j] >> 2) & 3;
+      const bool pad = (j % JB == JB - 1) && (code[j] & 3) == 3;      // padding lanes hold x = 0: the V terms vanish by themselves
       const double xv = x[j];
       double fj = 0.0, gj = 0.0;
       if (blk == 0) {
@@ -525,14 +543,16 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           fj = q.wp * (e * e);
           if (code[j] & 16) fj += q.term * q.wp * (e * e);
           gj = 2.0 * q.wp * e;
+          if (pad) { fj = 0.0; gj = 0.0; }
         }
       } else if (blk == 1) {
         fj = q.wv * (xv * xv); gj = 2.0 * q.wv * xv;
-      } else if (blk == 2) {
+      } else {
         const double ac = xv / q.mass - (a == 2 ? q.grav : 0.0);
         const double dv = xv - (a == 2 ? q.hover : 0.0);
         fj = q.wa * (ac * ac) + q.wT * (dv * dv);
         gj = 2.0 * q.wT * xv;
+        if (pad) fj = 0.0;
       }
       part += fj;
       g[j] = gj;
@@ -554,7 +574,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
     for (int j = 0; j < J; ++j) {
       double lo, hi;
-      elem_bounds(q, code[j], lo, hi);
+      slot_bounds<J>(q, j, code[j], lo, hi);
       double gi = g[j];
       if ((code[j] & 3) == 3) gi = 0.0;
       else if (gi < 0.0) gi = fmax(x[j] - hi, gi);
@@ -595,7 +615,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         double lo, hi;
-        elem_bounds(q, code[j], lo, hi);
+        slot_bounds<J>(q, j, code[j], lo, hi);
         const double neggi = -g[j];
         tbp[j] = kInf;
         double tl = 0.0, tu = 0.0;
@@ -634,7 +654,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             if (iwhere[j] == 0) {
               if (tbp[j] <= tstar) {
                 double lo, hi;
-                elem_bounds(q, code[j], lo, hi);
+                slot_bounds<J>(q, j, code[j], lo, hi);
                 if (d[j] > 0.0) { z[j] = hi; iwhere[j] = 2; } else { z[j] = lo; iwhere[j] = 1; }
                 d[j] = 0.0;
               } else {
@@ -712,7 +732,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             for (int j = 0; j < J; ++j) {
               if (j == jsel && lane == src) {
                 double lo, hi;
-                elem_bounds(q, code[j], lo, hi);
+                slot_bounds<J>(q, j, code[j], lo, hi);
                 dib = d[j]; d[j] = 0.0; tbp[j] = kInf;
                 if (dib > 0.0) { zib = hi - x[j]; z[j] = hi; iwhere[j] = 2; }
                 else { zib = lo - x[j]; z[j] = lo; iwhere[j] = 1; }
@@ -994,7 +1014,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             if (iwhere[j] <= 0) {
               d[j] *= rth;
               double lo, hi;
-              elem_bounds(q, code[j], lo, hi);
+              slot_bounds<J>(q, j, code[j], lo, hi);
               const double xk = fmin(hi, fmax(lo, z[j] + d[j]));
               z[j] = xk;
               if (xk == lo || xk == hi) hitp = true;
@@ -1013,7 +1033,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
                 z[j] = xo[j];
                 if (iwhere[j] <= 0) {
                   double lo, hi;
-                  elem_bounds(q, code[j], lo, hi);
+                  slot_bounds<J>(q, j, code[j], lo, hi);
                   const double dk = d[j];
                   double cand = 1.0;
                   if (dk < 0.0) { const double t2 = lo - z[j]; cand = (t2 >= 0.0) ? 0.0 : ((dk * 1.0 < t2) ? t2 / dk : 1.0); }
@@ -1028,7 +1048,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
                 if (iwhere[j] <= 0) {
                   if (alpha < 1.0 && (unsigned)(lane + kWave * j) == ibd) {
                     double lo, hi;
-                    elem_bounds(q, code[j], lo, hi);
+                    slot_bounds<J>(q, j, code[j], lo, hi);
                     if (d[j] > 0.0) { z[j] = hi; d[j] = 0.0; }
                     else if (d[j] < 0.0) { z[j] = lo; d[j] = 0.0; }
                   }
@@ -1058,7 +1078,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         double lo, hi;
-        elem_bounds(q, code[j], lo, hi);
+        slot_bounds<J>(q, j, code[j], lo, hi);
         const double a1 = d[j];
         if (a1 < 0.0) { const double a2 = lo - x[j]; if (a2 >= 0.0) smx = 0.0; else if (a1 * smx < a2) smx = a2 / a1; }
         else if (a1 > 0.0) { const double a2 = hi - x[j]; if (a2 <= 0.0) smx = 0.0; else if (a1 * smx > a2) smx = a2 / a1; }
@@ -1229,8 +1249,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   // ===================================================================== results
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int i = lane + kWave * j;
-    if (i < n) Xg[(size_t)pb * n + i] = (IO)x[j];
+    const int r = lane + kWave * (j % JB);
+    if (r < n3) Xg[(size_t)pb * n + (j / JB) * n3 + r] = (IO)x[j];
   }
   if (lane == 0 && infog != nullptr) {
     se3mpc_solve_info r;
@@ -1240,10 +1260,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   // ---- _extract_solution_from_result (planner.py:582-654): T block -> LDS, lane k = step k
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int i = lane + kWave * j;
-    if ((code[j] & 3) == 2) {
-      const int r = i - 6 * N;
+  for (int j = 2 * JB; j < J; ++j) {
+    const int r = lane + kWave * (j % JB);
+    if (r < n3) {
       scratch[r] = x[j];
       if (accg != nullptr) accg[(size_t)pb * 3 * N + r] = (IO)(x[j] / q.mass - (((code[j] >> 2) & 3) == 2 ? q.grav : 0.0));
     }
@@ -1327,18 +1346,15 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   if (!p0 || !v0 || !X || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
   SolveDev q = make_solve_dev(*p);
   q.seq_cauchy = g_solver_variant & 1;
-  const int n = q.n;
-  const int Jneed = (n + kWave - 1) / kWave;
+  const int JB = (3 * q.N + kWave - 1) / kWave;           // register slots per block of the decision vector (slot layout above)
+  if (JB > 3) return SE3MPC_ERR_SHAPE;                    // horizon <= 64 (check_params_impl says the same)
   hipStream_t s = (hipStream_t)stream;
 #define SE3MPC_SOLVE_CASE(JJ)                                                                                            \
   hipLaunchKernelGGL((solve_kernel<IO, JJ>), dim3(B), dim3(kWave), solve_lds_bytes(q.mlds, JJ, sizeof(IO)), s, q, B, p0, \
                      v0, goal, x0, X, info, acc, att, rates, thrust)
-#define SE3MPC_SOLVE_LAUNCH()                  \
-  if (Jneed <= 1) SE3MPC_SOLVE_CASE(1);        \
-  else if (Jneed <= 2) SE3MPC_SOLVE_CASE(2);   \
-  else if (Jneed <= 3) SE3MPC_SOLVE_CASE(3);   \
-  else if (Jneed <= 5) SE3MPC_SOLVE_CASE(5);   \
-  else if (Jneed <= 8) SE3MPC_SOLVE_CASE(8);   \
+#define SE3MPC_SOLVE_LAUNCH()               \
+  if (JB == 1) SE3MPC_SOLVE_CASE(3);        \
+  else if (JB == 2) SE3MPC_SOLVE_CASE(6);   \
   else SE3MPC_SOLVE_CASE(9)
   constexpr int kFastPairs = 4;
   // Two tiers buy occupancy (two resident solves per SIMD instead of one); up to one wavefront per SIMD of
