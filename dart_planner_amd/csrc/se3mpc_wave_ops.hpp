@@ -1,9 +1,9 @@
 // se3mpc_wave_ops.hpp -- 64-lane wavefront reductions on CDNA4 with DPP (no LDS traffic).
 //
 // A reduction is 4 in-row butterfly steps (quad_perm xor1, xor2, row_half_mirror, row_mirror:
-// afterwards every lane of a 16-lane row holds the row result), then row_bcast:15 into rows 1,3
-// and row_bcast:31 into rows 2,3, after which lane 63 holds the wave result, which v_readlane
-// broadcasts through an SGPR.  64-bit values move as two 32-bit DPP movs per step.
+// afterwards every lane of a 16-lane row holds the row result), then row_bcast:15 (each row's last
+// lane into the next row) and row_bcast:31 (lane 31 into rows 2,3), after which lane 63 holds the
+// wave result, which v_readlane broadcasts through an SGPR.  64-bit values move as two 32-bit DPP movs per step.
 // (tests/emu shadows this header with a host implementation of the same functions.)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -18,15 +18,19 @@ constexpr int kDppRowMirror = 0x140;
 constexpr int kDppRowBcast15 = 0x142;
 constexpr int kDppRowBcast31 = 0x143;
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+// One DPP move without a tied `old` operand: every lane whose source exists takes it, a lane without one (rows 0 / 0-1 of the two
+// row_bcast steps) reads 0 (bound_ctrl).  Only lane 63 is read at the end, and each of the six steps gives lane 63 a real source, so
+// what the other lanes accumulate does not matter -- and the compiler no longer has to initialise a destination (the identity of the
+// reduction) before each of the twelve moves of a 64-bit reduction, as it did with `update_dpp(identity, v, ...)` and row masks.
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double old, double v) {
-  const uint64_t o = (uint64_t)__double_as_longlong(old), x = (uint64_t)__double_as_longlong(v);
-  const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)o, (uint32_t)x);
-  const uint32_t hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(o >> 32), (uint32_t)(x >> 32));
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const uint64_t x = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = dpp_u32<CTRL>((uint32_t)x);
+  const uint32_t hi = dpp_u32<CTRL>((uint32_t)(x >> 32));
   return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
 }
 __device__ __forceinline__ double readlane63_f64(double v) {
@@ -38,12 +42,12 @@ __device__ __forceinline__ double readlane63_f64(double v) {
 
 // Sum over the 64 lanes, result in every lane.  All 64 lanes must be active.
 __device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_f64<kDppQuadXor1, 0xF>(0.0, v);
-  v += dpp_f64<kDppQuadXor2, 0xF>(0.0, v);
-  v += dpp_f64<kDppRowHalfMirror, 0xF>(0.0, v);
-  v += dpp_f64<kDppRowMirror, 0xF>(0.0, v);
-  v += dpp_f64<kDppRowBcast15, 0xA>(0.0, v);
-  v += dpp_f64<kDppRowBcast31, 0xC>(0.0, v);
+  v += dpp_f64<kDppQuadXor1>(v);
+  v += dpp_f64<kDppQuadXor2>(v);
+  v += dpp_f64<kDppRowHalfMirror>(v);
+  v += dpp_f64<kDppRowMirror>(v);
+  v += dpp_f64<kDppRowBcast15>(v);
+  v += dpp_f64<kDppRowBcast31>(v);
   return readlane63_f64(v);
 }
 
@@ -52,61 +56,59 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <int K>
 __device__ __forceinline__ void wave_sum_n(double (&v)[K]) {
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppQuadXor1, 0xF>(0.0, v[k]);
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppQuadXor1>(v[k]);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppQuadXor2, 0xF>(0.0, v[k]);
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppQuadXor2>(v[k]);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowHalfMirror, 0xF>(0.0, v[k]);
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowHalfMirror>(v[k]);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowMirror, 0xF>(0.0, v[k]);
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowMirror>(v[k]);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowBcast15, 0xA>(0.0, v[k]);
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowBcast15>(v[k]);
 #pragma unroll
-  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowBcast31, 0xC>(0.0, v[k]);
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowBcast31>(v[k]);
 #pragma unroll
   for (int k = 0; k < K; ++k) v[k] = readlane63_f64(v[k]);
 }
 
 __device__ __forceinline__ double wave_max(double v) {
-  const double ninf = -__builtin_huge_val();
-  v = fmax(v, dpp_f64<kDppQuadXor1, 0xF>(ninf, v));
-  v = fmax(v, dpp_f64<kDppQuadXor2, 0xF>(ninf, v));
-  v = fmax(v, dpp_f64<kDppRowHalfMirror, 0xF>(ninf, v));
-  v = fmax(v, dpp_f64<kDppRowMirror, 0xF>(ninf, v));
-  v = fmax(v, dpp_f64<kDppRowBcast15, 0xA>(ninf, v));
-  v = fmax(v, dpp_f64<kDppRowBcast31, 0xC>(ninf, v));
+  v = fmax(v, dpp_f64<kDppQuadXor1>(v));
+  v = fmax(v, dpp_f64<kDppQuadXor2>(v));
+  v = fmax(v, dpp_f64<kDppRowHalfMirror>(v));
+  v = fmax(v, dpp_f64<kDppRowMirror>(v));
+  v = fmax(v, dpp_f64<kDppRowBcast15>(v));
+  v = fmax(v, dpp_f64<kDppRowBcast31>(v));
   return readlane63_f64(v);
 }
 
 __device__ __forceinline__ double wave_min(double v) {
-  const double pinf = __builtin_huge_val();
-  v = fmin(v, dpp_f64<kDppQuadXor1, 0xF>(pinf, v));
-  v = fmin(v, dpp_f64<kDppQuadXor2, 0xF>(pinf, v));
-  v = fmin(v, dpp_f64<kDppRowHalfMirror, 0xF>(pinf, v));
-  v = fmin(v, dpp_f64<kDppRowMirror, 0xF>(pinf, v));
-  v = fmin(v, dpp_f64<kDppRowBcast15, 0xA>(pinf, v));
-  v = fmin(v, dpp_f64<kDppRowBcast31, 0xC>(pinf, v));
+  v = fmin(v, dpp_f64<kDppQuadXor1>(v));
+  v = fmin(v, dpp_f64<kDppQuadXor2>(v));
+  v = fmin(v, dpp_f64<kDppRowHalfMirror>(v));
+  v = fmin(v, dpp_f64<kDppRowMirror>(v));
+  v = fmin(v, dpp_f64<kDppRowBcast15>(v));
+  v = fmin(v, dpp_f64<kDppRowBcast31>(v));
   return readlane63_f64(v);
 }
 
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
   auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
-  v = mn(v, dpp_u32<kDppQuadXor1, 0xF>(0xFFFFFFFFu, v));
-  v = mn(v, dpp_u32<kDppQuadXor2, 0xF>(0xFFFFFFFFu, v));
-  v = mn(v, dpp_u32<kDppRowHalfMirror, 0xF>(0xFFFFFFFFu, v));
-  v = mn(v, dpp_u32<kDppRowMirror, 0xF>(0xFFFFFFFFu, v));
-  v = mn(v, dpp_u32<kDppRowBcast15, 0xA>(0xFFFFFFFFu, v));
-  v = mn(v, dpp_u32<kDppRowBcast31, 0xC>(0xFFFFFFFFu, v));
+  v = mn(v, dpp_u32<kDppQuadXor1>(v));
+  v = mn(v, dpp_u32<kDppQuadXor2>(v));
+  v = mn(v, dpp_u32<kDppRowHalfMirror>(v));
+  v = mn(v, dpp_u32<kDppRowMirror>(v));
+  v = mn(v, dpp_u32<kDppRowBcast15>(v));
+  v = mn(v, dpp_u32<kDppRowBcast31>(v));
   return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 __device__ __forceinline__ int wave_sum_i32(int v) {
-  v += (int)dpp_u32<kDppQuadXor1, 0xF>(0u, (uint32_t)v);
-  v += (int)dpp_u32<kDppQuadXor2, 0xF>(0u, (uint32_t)v);
-  v += (int)dpp_u32<kDppRowHalfMirror, 0xF>(0u, (uint32_t)v);
-  v += (int)dpp_u32<kDppRowMirror, 0xF>(0u, (uint32_t)v);
-  v += (int)dpp_u32<kDppRowBcast15, 0xA>(0u, (uint32_t)v);
-  v += (int)dpp_u32<kDppRowBcast31, 0xC>(0u, (uint32_t)v);
+  v += (int)dpp_u32<kDppQuadXor1>((uint32_t)v);
+  v += (int)dpp_u32<kDppQuadXor2>((uint32_t)v);
+  v += (int)dpp_u32<kDppRowHalfMirror>((uint32_t)v);
+  v += (int)dpp_u32<kDppRowMirror>((uint32_t)v);
+  v += (int)dpp_u32<kDppRowBcast15>((uint32_t)v);
+  v += (int)dpp_u32<kDppRowBcast31>((uint32_t)v);
   return __builtin_amdgcn_readlane(v, 63);
 }
 

@@ -514,6 +514,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     x[j] = fmin(fmax(xv, lo), hi);
     g[j] = 0.0; z[j] = x[j]; d[j] = 0.0; xo[j] = x[j]; go[j] = 0.0;
   }
+  // the goal coordinate of every position slot's element, selected once (the objective asks for it at every evaluation)
+  double gsel[JB];
+#pragma unroll
+  for (int j = 0; j < JB; ++j) gsel[j] = goal_of(code[j]);
 
   // objective (planner.py:516-550) and the reference's gradient (planner.py:552-580) at x
   // nfev counts like scipy's ScalarFunction: asking again for the x evaluated last (a line search
@@ -539,7 +543,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       double fj = 0.0, gj = 0.0;
       if (blk == 0) {
         if (q.has_goal) {
-          const double e = xv - goal_of(code[j]);
+          const double e = xv - gsel[j % JB];
           fj = q.wp * (e * e);
           if (code[j] & 16) fj += q.term * q.wp * (e * e);
           gj = 2.0 * q.wp * e;
@@ -575,10 +579,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     for (int j = 0; j < J; ++j) {
       double lo, hi;
       slot_bounds<J>(q, j, code[j], lo, hi);
-      double gi = g[j];
-      if ((code[j] & 3) == 3) gi = 0.0;
-      else if (gi < 0.0) gi = fmax(x[j] - hi, gi);
-      else gi = fmin(x[j] - lo, gi);
+      const double gj = g[j];
+      const double up = fmax(x[j] - hi, gj), dn = fmin(x[j] - lo, gj);      // both sides, then one select: no divergent branches
+      double gi = gj < 0.0 ? up : dn;
+      if (j % JB == JB - 1 && (code[j] & 3) == 3) gi = 0.0;
       mx = fmax(mx, fabs(gi));
     }
     return wave_max(mx);
@@ -614,29 +618,24 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       int nbr = 0;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
+        // written as value selects throughout: as nested ifs this loop became ~50 exec-mask instructions per slot
         double lo, hi;
         slot_bounds<J>(q, j, code[j], lo, hi);
         const double neggi = -g[j];
-        tbp[j] = kInf;
-        double tl = 0.0, tu = 0.0;
-        if (iwhere[j] != 3) {
-          tl = x[j] - lo; tu = hi - x[j];
-          const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
-          iwhere[j] = 0;
-          if (xlower) { if (neggi <= 0.0) iwhere[j] = 1; }
-          else if (xupper) { if (neggi >= 0.0) iwhere[j] = 2; }
-          else if (fabs(neggi) <= 0.0) iwhere[j] = -3;
-        }
-        if (iwhere[j] != 0) {
-          d[j] = 0.0;
-        } else {
-          d[j] = neggi;
-          f1p -= neggi * neggi;
-          if (neggi != 0.0) {                                 // one division: tl / (-neggi) for a descending, tu / neggi for an ascending variable
-            tbp[j] = (neggi < 0.0 ? tl : tu) / fabs(neggi);
-            ++nbr;
-          }
-        }
+        const double tl = x[j] - lo, tu = hi - x[j];
+        const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
+        const int atlo = neggi <= 0.0 ? 1 : 0, athi = neggi >= 0.0 ? 2 : 0, flat = fabs(neggi) <= 0.0 ? -3 : 0;
+        const int iwb = xlower ? atlo : (xupper ? athi : flat);
+        const int iw = iwhere[j] != 3 ? iwb : 3;
+        iwhere[j] = iw;
+        const bool moving = iw == 0;
+        const double dj = moving ? neggi : 0.0;
+        d[j] = dj;
+        f1p -= dj * dj;
+        const bool brk = moving && neggi != 0.0;          // one division: tl / (-neggi) for a descending, tu / neggi for an ascending variable
+        const double quot = (neggi < 0.0 ? tl : tu) / fabs(neggi);
+        tbp[j] = brk ? quot : kInf;
+        nbr += brk ? 1 : 0;
         z[j] = x[j];
       }
       if (col == 0 && !q.seq_cauchy) {
@@ -651,16 +650,13 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           const double tstar = 1.0 / theta;
 #pragma unroll
           for (int j = 0; j < J; ++j) {
-            if (iwhere[j] == 0) {
-              if (tbp[j] <= tstar) {
-                double lo, hi;
-                slot_bounds<J>(q, j, code[j], lo, hi);
-                if (d[j] > 0.0) { z[j] = hi; iwhere[j] = 2; } else { z[j] = lo; iwhere[j] = 1; }
-                d[j] = 0.0;
-              } else {
-                z[j] += tstar * d[j];
-              }
-            }
+            double lo, hi;
+            slot_bounds<J>(q, j, code[j], lo, hi);
+            const bool hit = iwhere[j] == 0 && tbp[j] <= tstar;          // d is 0 wherever iwhere != 0: z + tstar*d leaves those alone
+            const bool upw = d[j] > 0.0;
+            z[j] = hit ? (upw ? hi : lo) : z[j] + tstar * d[j];
+            iwhere[j] = hit ? (upw ? 2 : 1) : iwhere[j];
+            d[j] = hit ? 0.0 : d[j];
           }
         }
       } else {
@@ -1011,14 +1007,14 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             xo[j] = z[j];
-            if (iwhere[j] <= 0) {
-              d[j] *= rth;
-              double lo, hi;
-              slot_bounds<J>(q, j, code[j], lo, hi);
-              const double xk = fmin(hi, fmax(lo, z[j] + d[j]));
-              z[j] = xk;
-              if (xk == lo || xk == hi) hitp = true;
-            }
+            const bool fr = iwhere[j] <= 0;
+            double lo, hi;
+            slot_bounds<J>(q, j, code[j], lo, hi);
+            const double dn = d[j] * rth;
+            const double xk = fmin(hi, fmax(lo, z[j] + dn));
+            d[j] = fr ? dn : d[j];
+            z[j] = fr ? xk : z[j];
+            hitp = hitp || (fr && (xk == lo || xk == hi));
             ddp += (z[j] - x[j]) * g[j];
           }
           const bool iword = wave_ballot(hitp) != 0ull;
@@ -1080,8 +1076,12 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         double lo, hi;
         slot_bounds<J>(q, j, code[j], lo, hi);
         const double a1 = d[j];
-        if (a1 < 0.0) { const double a2 = lo - x[j]; if (a2 >= 0.0) smx = 0.0; else if (a1 * smx < a2) smx = a2 / a1; }
-        else if (a1 > 0.0) { const double a2 = hi - x[j]; if (a2 <= 0.0) smx = 0.0; else if (a1 * smx > a2) smx = a2 / a1; }
+        const bool neg = a1 < 0.0, pos = a1 > 0.0;
+        const double a2 = neg ? lo - x[j] : hi - x[j];
+        const bool blocked = neg ? a2 >= 0.0 : (pos && a2 <= 0.0);
+        const bool tighter = neg ? a1 * smx < a2 : (pos && a1 * smx > a2);
+        const double quot = a2 / a1;
+        smx = blocked ? 0.0 : (tighter ? quot : smx);
       }
       stpmx = wave_min(smx);
     }
