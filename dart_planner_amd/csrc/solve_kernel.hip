@@ -23,13 +23,16 @@
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
 
-// -DSE3MPC_SOLVE_PROFILE (tools/gpu_profile_solve_sections.sh, never the shipped build): per-section cycle sums of every wavefront, written over
-// the first 64 bytes of its `thrust` output row.  Sections: 0 start-up + first evaluation, 1 later evaluations, 2 Cauchy point, 3 subspace
-// minimisation, 4 line search without its evaluations, 5 convergence tests + BFGS update, 6 results, 7 total.
+// -DSE3MPC_SOLVE_PROFILE (tools/build_solve_profile.sh + tools/gpu_profile_solve_sections.py, never the shipped build): per-section cycle sums of every wavefront, written over
+// the first 128 bytes of its `attitudes` output row.  Sections: 0 start-up + first evaluation, 1 later evaluations, 2 Cauchy point (rest), 3 subspace
+// minimisation (rest), 4 line search without its evaluations, 5 convergence tests + BFGS update, 6 results, 7 total; 8 Cauchy pass 1, 9 closed-form
+// pass, 10 p = W'd + first bmv, 11 breakpoint loop, 12 subspace formk + factor, 13 line search set-up (d, dtd, stpmx), 15 = number of crossings.
 #ifdef SE3MPC_SOLVE_PROFILE
-#define SE3MPC_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); tsec[i] += now_ - tlast; tlast = now_; }
+#define SE3MPC_TICK(i) { const unsigned long long now_ = __builtin_readcyclecounter(); if (lane == 0) tsec[i] += now_ - tlast; tlast = now_; }
+#define SE3MPC_COUNT(i) { if (lane == 0) tsec[i] += 1; }
 #else
 #define SE3MPC_TICK(i)
+#define SE3MPC_COUNT(i)
 #endif
 
 #ifndef SE3MPC_SOLVE_WAVES
@@ -469,7 +472,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   const double vs0 = cold ? (double)v0g[pb * 3 + 0] : 0.0, vs1 = cold ? (double)v0g[pb * 3 + 1] : 0.0, vs2 = cold ? (double)v0g[pb * 3 + 2] : 0.0;
 
 #ifdef SE3MPC_SOLVE_PROFILE
-  unsigned long long tsec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  __shared__ unsigned long long tsec[16];                     // in LDS (lane 0 adds): eight SGPR pairs of counters would change the register allocation measured
+  if (lane < 16) tsec[lane] = 0;
+  __syncthreads();
   unsigned long long tlast = __builtin_readcyclecounter();
   const unsigned long long tstart = tlast;
 #endif
@@ -638,6 +643,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         nbr += brk ? 1 : 0;
         z[j] = x[j];
       }
+      SE3MPC_TICK(8)
       if (col == 0 && !q.seq_cauchy) {
         // No L-BFGS pairs yet: B = theta*I and the piecewise quadratic along the projected path is
         //   m(t) = sum_i g_i^2 (theta*tau_i^2/2 - tau_i),  tau_i = min(t, t_i),
@@ -659,6 +665,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             d[j] = hit ? 0.0 : d[j];
           }
         }
+        SE3MPC_TICK(9)
       } else {
       double f1 = wave_sum(f1p);
       const int nbreak = wave_sum_i32(nbr);
@@ -703,6 +710,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           f2 -= sc[0];
           __syncthreads();
         }
+        SE3MPC_TICK(10)
         if (info == 0) {
           double dtm = -f1 / f2, tsum = 0.0, tj = 0.0;
           int nleft = nbreak;
@@ -722,6 +730,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             if (dtm < dt) break;
             tsum += dt;
             --nleft;
+            SE3MPC_COUNT(15)
             // owner fixes its variable at the bound it hits
             double dib = 0.0, zib = 0.0;
 #pragma unroll
@@ -791,6 +800,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             if (nleft > 0) dtm = -f1 / f2;
             else { f1 = 0.0; f2 = 0.0; dtm = 0.0; }       // every variable with d != 0 has hit a bound
           }
+          SE3MPC_TICK(11)
           if (info == 0) {
             if (!all_fixed) {
               if (dtm <= 0.0) dtm = 0.0;
@@ -859,6 +869,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             }
           }
           int inf = formk_factor_regs<C>(wnr);
+          SE3MPC_TICK(12)
           // ---- cmprlb, scalar part: mc = M c
           MidRegs<C> M;
           load_mid<C>(sy, wt, m, M);
@@ -1088,6 +1099,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     double stp = 1.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) { xo[j] = x[j]; go[j] = g[j]; }
+    SE3MPC_TICK(13)
     fold = f;
     int ifun = 0, iback = 0, ls_info = 0;
     double gd = 0.0, gdold = 0.0;
@@ -1257,6 +1269,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     r.fun = f; r.nit = nit; r.nfev = nfev; r.status = status; r.task = task;
     infog[pb] = r;
   }
+  // a restart solve asks for x and info only (every trajectory output null): nothing to extract
+  if (accg == nullptr && attg == nullptr && ratesg == nullptr && thrustg == nullptr) return;
   // ---- _extract_solution_from_result (planner.py:582-654): T block -> LDS, lane k = step k
   __syncthreads();
 #pragma unroll
@@ -1317,10 +1331,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #ifdef SE3MPC_SOLVE_PROFILE
   __syncthreads();
   SE3MPC_TICK(6)
-  tsec[7] = tlast - tstart;
-  if (lane == 0 && thrustg != nullptr && (size_t)N * sizeof(IO) >= 64) {
-    unsigned long long* dst = reinterpret_cast<unsigned long long*>(thrustg + (size_t)pb * N);
-    for (int i = 0; i < 8; ++i) dst[i] = tsec[i];
+  if (lane == 0) tsec[7] = tlast - tstart;
+  __syncthreads();
+  if (lane == 0 && attg != nullptr && (size_t)3 * N * sizeof(IO) >= 128) {
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(attg + (size_t)pb * 3 * N);
+    for (int i = 0; i < 16; ++i) dst[i] = tsec[i];
   }
 #endif
 }
