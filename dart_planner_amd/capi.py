@@ -190,6 +190,10 @@ _LL = C.c_longlong
 # consumer side of the contract: se3mpc_<base>_<suffix>(...)
 _LOOP_TYPED_API = {
     "control": [_CP, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "control_fast": [_CP, _D, _D, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "controller_integral_update": [_CP, _I, _P, _D, _P, _P, _P],
+    "controller_attitude_torque": [_CP, _I, _P, _P, _P, _P, _P, C.POINTER(C.c_double * 9), _P, _P, _P, _P],
+    "controller_desired_frame": [_CP, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "control_plan": [_CP, _I, _P, _P, _P, _P, _P, _P, _I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P],
     "simulator_step": [_SP, _I, _D, _P, _P, _P, _LL, _P, _P, _P, _P, _P, _P],
     "closed_loop": [_CP, _SP, _I, _I, _D, _I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _LL, _I,

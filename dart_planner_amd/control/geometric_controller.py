@@ -79,7 +79,7 @@ class GeometricController:
     """controller.py:79-881 on the device, one drone."""
 
     def __init__(self, config: Optional[GeometricControllerConfig] = None, tuning_profile: str = "sitl_optimized", *,
-                 precision: str = "f64", device=None):
+                 precision: str = "f64", device=None, vehicle_mass: float = 1.0, vehicle_gravity: float = 9.80665):
         if config is None:
             config = GeometricControllerConfig()
         if tuning_profile:
@@ -93,6 +93,9 @@ class GeometricController:
         self.position_errors, self.velocity_errors, self.control_outputs = [], [], []
         self._thrust_saturation_count = 0
         self._torque_saturation_count = 0
+        # get_control_constants() (common/vehicle_params.py:68-77): what the fast path takes mass and gravity from (controller.py:118-127)
+        self._fast_mass, self._fast_gravity_magnitude = float(vehicle_mass), float(vehicle_gravity)
+        self._inertia_override = None
 
     def _apply_tuning_profile(self, config: GeometricControllerConfig, profile_name: str) -> None:   # controller.py:140-158
         prof = TUNING_PROFILES.get(profile_name)
@@ -138,8 +141,6 @@ class GeometricController:
 
     def _bookkeep(self, out):
         fl = int(out["flags"].cpu()[0])
-        self._thrust_saturation_count += int(bool(fl & 4))
-        self._torque_saturation_count += bin((fl >> 5) & 7).count("1")
         thrust = float(out["thrust"].cpu()[0])
         torque = out["torque"].cpu().numpy()[0].astype(float)
         if not fl & 1:
@@ -165,6 +166,24 @@ class GeometricController:
                                       want_body_rate=True)
         self._bookkeep(out)
         return BodyRateCommand(thrust=float(out["body_thrust"].cpu()[0]), body_rates=out["body_rates"].cpu().numpy()[0].astype(float))
+
+    # ------------------------------------------------------------------ controller.py:253-411, :728-768 (the 400 Hz hardware loop's path)
+    def compute_control_fast(self, pos, vel, att, ang_vel, desired_pos, desired_vel, desired_acc, desired_yaw: float = 0.0,
+                             desired_yaw_rate: float = 0.0, dt: float = 0.001):
+        """-> (thrust: float newtons, torque: ndarray (3,)).  Shares integral, halved gains and saturation flags with compute_control."""
+        row = lambda x: self._dev(np.asarray(x, float).reshape(1, 3))
+        out = self._get_ops().control_fast(self._params(), self._members(), float(dt), row(pos), row(vel), row(att), row(ang_vel), row(desired_pos),
+                                           row(desired_vel), row(desired_acc), self._dev([float(desired_yaw)]), self._dev([float(desired_yaw_rate)]),
+                                           vehicle_mass=self._fast_mass, vehicle_gravity=self._fast_gravity_magnitude)
+        fl = int(out["flags"].cpu()[0])
+        self._thrust_saturation_count += int(bool(fl & 4))               # :315, :319 (only this path counts)
+        self._torque_saturation_count += bin((fl >> 5) & 7).count("1")   # :404
+        return float(out["thrust"].cpu()[0]), out["torque"].cpu().numpy()[0].astype(float)
+
+    def compute_control_from_fast_state(self, fast_state, desired_pos, desired_vel, desired_acc, desired_yaw: float = 0.0,
+                                        desired_yaw_rate: float = 0.0, dt: float = 0.001):
+        return self.compute_control_fast(fast_state.position, fast_state.velocity, fast_state.attitude, fast_state.angular_velocity, desired_pos,
+                                         desired_vel, desired_acc, desired_yaw, desired_yaw_rate, dt)
 
     # ------------------------------------------------------------------ the glue of the contract test (reference: stub :873-875 / missing)
     def _plan_args(self, trajectory: Trajectory):
@@ -197,13 +216,71 @@ class GeometricController:
         self._state.copy_(keep)
         return tg[0:3], tg[3:6], tg[6:9], 0.0, 0.0
 
-    # ------------------------------------------------------------------ members of the reference class, read back from the device record
+    # ------------------------------------------------------------------ the building blocks the reference's controller tests call directly
+    FALLBACK_METHODS = {"skip_yaw": 0, "default_heading": 1, "maintain_current": 2}
+
+    @property
+    def _fast_inertia(self) -> np.ndarray:                   # controller.py:125; its tests assign a full matrix
+        return np.diag(np.asarray(self.config.inertia, float)) if self._inertia_override is None else self._inertia_override
+
+    @_fast_inertia.setter
+    def _fast_inertia(self, m) -> None:
+        self._inertia_override = np.asarray(m, float).reshape(3, 3)
+
+    def _update_integral_error(self, vel_error, dt: float, thrust_saturated: bool = False, torque_saturated=None) -> None:   # :536-564
+        sat = int(bool(thrust_saturated)) | sum((2 << i) for i in range(3) if torque_saturated is not None and bool(torque_saturated[i]))
+        import torch
+        ops = self._get_ops()
+        ops.controller_integral_update(self._params(), self._members(), self._dev(np.asarray(vel_error, float).reshape(1, 3)), float(dt),
+                                       torch.tensor([sat], dtype=torch.int32, device=ops.be.device))
+
+    def _attitude_torque(self, att, ang_vel, b3_des, yaw_des, yaw_rate_des, inertia):
+        row = lambda x: self._dev(np.asarray(to_float(x), float).reshape(1, 3))
+        out = self._get_ops().controller_attitude_torque(self._params(), self._members(), row(att), row(ang_vel), row(b3_des), self._dev([float(yaw_des)]),
+                                                         self._dev([float(yaw_rate_des)]), inertia=inertia)
+        return out["torque"].cpu().numpy()[0].astype(float), int(out["flags"].cpu()[0])
+
+    def _fast_geometric_attitude_control(self, att, ang_vel, b3_des, yaw_des: float, yaw_rate_des: float) -> np.ndarray:   # :348-411
+        torque, fl = self._attitude_torque(att, ang_vel, b3_des, yaw_des, yaw_rate_des, self._inertia_override)
+        self._torque_saturation_count += bin((fl >> 5) & 7).count("1")     # :404
+        return torque
+
+    def _geometric_attitude_control(self, state: DroneState, b3_des, yaw_des: float, yaw_rate_des: float, thrust_mag: float, dt: float):   # :643-704
+        torque, _ = self._attitude_torque(state.attitude, state.angular_velocity, b3_des, yaw_des, yaw_rate_des, None)
+        return thrust_mag, torque
+
+    def _frame(self, yaw_vector, b3_des, current_yaw, method: int):
+        row = lambda x: self._dev(np.asarray(x, float).reshape(1, 3))
+        out = self._get_ops().controller_desired_frame(self._params(), row(yaw_vector), row(b3_des), self._dev([float(current_yaw)]), method)
+        return out["frame"].cpu().numpy()[0].astype(float), float(out["cos_angle"].cpu()[0]), bool(int(out["singular"].cpu()[0]))
+
+    def _detect_yaw_singularity(self, yaw_vector, b3_des):   # :160-189
+        _, cos_angle, singular = self._frame(yaw_vector, b3_des, 0.0, -1)
+        return singular, cos_angle, self.config.yaw_singularity_fallback_method
+
+    def _handle_yaw_singularity(self, yaw_vector, b3_des, current_yaw: float, fallback_method: str):   # :191-252
+        f, _, _ = self._frame(yaw_vector, b3_des, current_yaw, self.FALLBACK_METHODS.get(fallback_method, 3))
+        return f[0:3], f[3:6], f[6:9]
+
+    # ------------------------------------------------------------------ members of the reference class, kept in the device record
     def _word(self, i):
         return float(self._members().cpu()[0, i])
+
+    def _set_words(self, lo: int, values) -> None:
+        import torch
+        st = self._members()
+        st[0, lo:lo + len(values)] = torch.as_tensor(np.asarray(values, float), dtype=st.dtype, device=st.device)
+
+    def _set_flag_bits(self, mask: int, bits: int) -> None:
+        self._set_words(11, [float((int(self._word(11)) & ~mask) | bits)])
 
     @property
     def integral_vel_error(self) -> np.ndarray:
         return self._members().cpu().numpy()[0, 0:3].astype(float)
+
+    @integral_vel_error.setter
+    def integral_vel_error(self, v) -> None:
+        self._set_words(0, np.asarray(v, float).reshape(3))
 
     @property
     def last_time(self):
@@ -232,10 +309,34 @@ class GeometricController:
     def last_thrust_saturated(self) -> bool:
         return bool(int(self._word(11)) & 2)
 
+    @last_thrust_saturated.setter
+    def last_thrust_saturated(self, v) -> None:
+        self._set_flag_bits(2, 2 if v else 0)
+
     @property
     def last_torque_saturated(self) -> np.ndarray:
         f = int(self._word(11))
         return np.array([bool(f & 4), bool(f & 8), bool(f & 16)])
+
+    @last_torque_saturated.setter
+    def last_torque_saturated(self, v) -> None:
+        self._set_flag_bits(4 | 8 | 16, sum((4 << i) for i in range(3) if bool(v[i])))
+
+    @property
+    def unsaturated_thrust(self) -> float:
+        return self._word(5)
+
+    @unsaturated_thrust.setter
+    def unsaturated_thrust(self, v) -> None:
+        self._set_words(5, [float(v)])
+
+    @property
+    def unsaturated_torque(self) -> np.ndarray:
+        return self._members().cpu().numpy()[0, 6:9].astype(float)
+
+    @unsaturated_torque.setter
+    def unsaturated_torque(self, v) -> None:
+        self._set_words(6, np.asarray(v, float).reshape(3))
 
     def reset(self) -> None:                                 # controller.py:840-860
         if self._state is not None:
@@ -243,12 +344,13 @@ class GeometricController:
         self.position_errors, self.velocity_errors, self.control_outputs = [], [], []
         self._thrust_saturation_count = self._torque_saturation_count = 0
 
-    def get_performance_metrics(self) -> dict:               # controller.py:830-838 (the keys that do not need the error logs)
+    def get_performance_metrics(self) -> dict:               # controller.py:821-851 (without the error logs the device does not keep)
         return {"anti_windup_method": self.config.anti_windup_method, "integral_magnitude": float(np.linalg.norm(self.integral_vel_error)),
                 "integral_per_axis": self.integral_vel_error.tolist(), "thrust_saturation_count": self._thrust_saturation_count,
                 "torque_saturation_count": self._torque_saturation_count, "failsafe_activations": self.failsafe_count,
                 "yaw_singularity_threshold": self.config.yaw_singularity_threshold,
-                "yaw_singularity_fallback_method": self.config.yaw_singularity_fallback_method}
+                "yaw_singularity_fallback_method": self.config.yaw_singularity_fallback_method,
+                "yaw_singularity_warning_threshold": self.config.yaw_singularity_warning_threshold}
 
 
 assert CONTROLLER_STATE_WORDS == 12

@@ -120,6 +120,128 @@ __device__ __forceinline__ void enter_failsafe(CtrlRegs<R>& s) {
 // Output flags of one control call.
 enum { CF_FAILSAFE = 1, CF_BAD_DT = 2, CF_THRUST_SAT = 4, CF_SINGULAR = 8, CF_TILT = 16, CF_TORQUE_SAT_X = 32 };
 
+// _update_integral_error (controller.py:548-578) with its anti-windup method and _clamp_integral_per_axis; the torque saturation flags
+// and unsaturated torques in `s` are still the previous call's (the current torque is computed afterwards, :480 vs :494).
+template <typename R>
+__device__ __forceinline__ void update_integral(const CtrlDev<R>& c, CtrlRegs<R>& s, const R ve[3], R dt, bool thrust_sat) {
+  R upd[3];
+  for (int i = 0; i < 3; ++i) upd[i] = ve[i] * dt;
+  if (c.anti_windup == 0) {                                                    // clamping (:580-598)
+    if (thrust_sat) for (int i = 0; i < 3; ++i) upd[i] = upd[i] * (R)0.1;
+    for (int i = 0; i < 3; ++i) if (s.flags & (4 << i)) upd[i] = upd[i] * (R)0.1;
+  } else if (c.anti_windup == 1) {                                             // back-calculation (:600-623)
+    if (thrust_sat) {
+      const R fb = (s.unsat_thrust - c.max_thrust) * c.kb;
+      upd[0] = upd[0] - fb * (R)0.33; upd[1] = upd[1] - fb * (R)0.33; upd[2] = upd[2] - fb * (R)0.34;
+    }
+    for (int i = 0; i < 3; ++i)
+      if (s.flags & (4 << i)) upd[i] = upd[i] - ((s.unsat_torque[i] - c.max_torque[i]) * c.kb) * (R)0.5;
+  }
+  R I[3];
+  for (int i = 0; i < 3; ++i) {
+    I[i] = s.integral[i] + upd[i];                                             // :574
+    if (fabs(I[i]) > c.max_int_axis[i]) I[i] = sign_of(I[i]) * c.max_int_axis[i];   // :630-632
+  }
+  const R mag = norm3(I);
+  if (mag > c.max_integral_pos) { const R f = c.max_integral_pos / mag; for (int i = 0; i < 3; ++i) I[i] = I[i] * f; }   // :635-637
+  for (int i = 0; i < 3; ++i) {
+    if (fabs(I[i]) > c.max_int_axis[i] * c.sat_thr) I[i] = I[i] * c.decay;     // :640-643
+    s.integral[i] = I[i];
+  }
+}
+
+// _detect_yaw_singularity (controller.py:160-189) and the desired frame of _geometric_attitude_control: the normal construction
+// (:680-689) or, when |yaw_vector . b3| >= the threshold (or `force`: a direct _handle_yaw_singularity call), the fallback `method`
+// (:191-257; 0 skip_yaw, 1 default_heading, 2 maintain_current, 3 any other string).  b3n as given (the callers normalise it, :667);
+// (cy, sy) = cos / sin of the CURRENT yaw.
+template <typename R>
+__device__ __forceinline__ void desired_frame(const CtrlDev<R>& c, int method, bool force, const R yv[3], const R b3n[3], R cy, R sy, R b1[3],
+                                              R b2[3], R& cos_angle, bool& singular) {
+  cos_angle = fabs((yv[0] * b3n[0] + yv[1] * b3n[1]) + yv[2] * b3n[2]);            // :174
+  singular = cos_angle >= c.yaw_sing_thr;                                         // :177
+  if (singular || force) {                                                        // :191-257
+    R proj[3] = {(R)1 - b3n[0] * b3n[0], (R)0 - b3n[0] * b3n[1], (R)0 - b3n[0] * b3n[2]};   // [1,0,0] - ([1,0,0].b3) b3
+    const R np_ = norm3(proj);
+    proj[0] = proj[0] / np_; proj[1] = proj[1] / np_; proj[2] = proj[2] / np_;
+    if (method == 1 || method == 2) {                                             // default_heading / maintain_current
+      const R hv[3] = {method == 1 ? c.dh_cos : cy, method == 1 ? c.dh_sin : sy, (R)0};
+      R cx[3];
+      cross3(hv, b3n, cx);
+      const R nc = norm3(cx);
+      if (nc > (R)1e-6) { b1[0] = cx[0] / nc; b1[1] = cx[1] / nc; b1[2] = cx[2] / nc; }
+      else { b1[0] = proj[0]; b1[1] = proj[1]; b1[2] = proj[2]; }
+    } else if (method != 0 || fabs(b3n[2]) < (R)0.99) {                           // skip_yaw (:212-217); unknown methods (:248-252)
+      b1[0] = proj[0]; b1[1] = proj[1]; b1[2] = proj[2];
+    } else {                                                                      // :218-220
+      b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0;
+    }
+  } else {                                                                        // :680-688
+    cross3(yv, b3n, b1);
+    const R n1 = norm3(b1);
+    if (n1 > (R)1e-6) { b1[0] = b1[0] / n1; b1[1] = b1[1] / n1; b1[2] = b1[2] / n1; }
+    else { b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0; }
+  }
+  cross3(b3n, b1, b2);                                                            // :255 / :689
+}
+
+// _geometric_attitude_control (controller.py:660-715) == _fast_geometric_attitude_control (:348-411): torque command, unsaturated
+// torques and the torque saturation flags of `s`.  b3 = desired thrust direction (normalised here, :667), scale = 0.5 ** failsafe
+// halvings, Ifull = a full 3x3 inertia (row-major; the reference's tests assign one to _fast_inertia) or nullptr = diag(c.inertia).
+template <typename R>
+__device__ void attitude_torque(const CtrlDev<R>& c, CtrlRegs<R>& s, R scale, const R b3[3], const R att[3], const R omega[3], R yaw_des,
+                                R yaw_rate_des, const R* Ifull, R torque_out[3], int& out_flags) {
+  const R cr = cos(att[0]), sr = sin(att[0]), cp = cos(att[1]), sp = sin(att[1]), cy = cos(att[2]), sy = sin(att[2]);
+  const R Rm[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},   // :774-789
+                      {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
+                      {-sp, cp * sr, cp * cr}};
+  const R yv[3] = {cos(yaw_des), sin(yaw_des), (R)0};                             // :665
+  const R n3 = norm3(b3);
+  const R b3n[3] = {b3[0] / n3, b3[1] / n3, b3[2] / n3};                          // :667
+  R b1[3], b2[3], cos_angle;
+  bool singular;
+  desired_frame(c, c.fallback, false, yv, b3n, cy, sy, b1, b2, cos_angle, singular);
+  if (singular) out_flags |= CF_SINGULAR;
+  const R Rd[3][3] = {{b1[0], b2[0], b3n[0]}, {b1[1], b2[1], b3n[1]}, {b1[2], b2[2], b3n[2]}};   // column_stack
+  // eR = 0.5 vee(Rd^T R - R^T Rd) (:692): vee(M) = (M21, M02, M10)
+  auto dtr = [&](const R A_[3][3], const R B_[3][3], int i, int j) { return (A_[0][i] * B_[0][j] + A_[1][i] * B_[1][j]) + A_[2][i] * B_[2][j]; };
+  const R eR[3] = {(R)0.5 * (dtr(Rd, Rm, 2, 1) - dtr(Rm, Rd, 2, 1)), (R)0.5 * (dtr(Rd, Rm, 0, 2) - dtr(Rm, Rd, 0, 2)),
+                   (R)0.5 * (dtr(Rd, Rm, 1, 0) - dtr(Rm, Rd, 1, 0))};
+  const R eO[3] = {omega[0], omega[1], omega[2] - yaw_rate_des};                  // :693-695
+  R Iw[3];
+  if (Ifull != nullptr) for (int i = 0; i < 3; ++i) Iw[i] = (Ifull[3 * i] * omega[0] + Ifull[3 * i + 1] * omega[1]) + Ifull[3 * i + 2] * omega[2];
+  else for (int i = 0; i < 3; ++i) Iw[i] = c.inertia[i] * omega[i];
+  R cor[3];
+  cross3(omega, Iw, cor);                                                         // :700
+  int tsat = 0;
+  for (int i = 0; i < 3; ++i) {
+    R tq = (-(c.kp_att[i] * scale) * eR[i] - (c.kd_att[i] * scale) * eO[i]) + cor[i];   // :701
+    s.unsat_torque[i] = tq;                                                       // :704
+    if (fabs(tq) > c.max_torque[i]) { tq = sign_of(tq) * c.max_torque[i]; tsat |= (4 << i); }   // :708-711
+    torque_out[i] = tq;
+  }
+  s.flags = (s.flags & ~(4 | 8 | 16)) | tsat;                                     // :713
+  out_flags |= (tsat >> 2) * CF_TORQUE_SAT_X;
+}
+
+// The desired thrust direction with the tilt limit (controller.py:487-496 == :328-339 of the fast path), then the attitude law.
+// tvw = thrust vector (world), tm = its SATURATED magnitude.
+template <typename R>
+__device__ void attitude_command(const CtrlDev<R>& c, CtrlRegs<R>& s, R scale, const R tvw[3], R tm, const R att[3], const R omega[3],
+                                 R yaw_des, R yaw_rate_des, R torque_out[3], int& out_flags) {
+  R b3[3];
+  if (tm > (R)1e-6) { b3[0] = tvw[0] / tm; b3[1] = tvw[1] / tm; b3[2] = tvw[2] / tm; }
+  else { b3[0] = (R)0; b3[1] = (R)0; b3[2] = (R)1; }
+  const R tilt = acos(fmin(fmax(b3[2], (R)-1), (R)1));
+  if (tilt > c.max_tilt) {
+    const R sf = c.cos_max_tilt / b3[2];
+    b3[0] = b3[0] * sf; b3[1] = b3[1] * sf; b3[2] = c.cos_max_tilt;
+    const R n = norm3(b3);
+    b3[0] = b3[0] / n; b3[1] = b3[1] / n; b3[2] = b3[2] / n;
+    out_flags |= CF_TILT;
+  }
+  attitude_torque(c, s, scale, b3, att, omega, yaw_des, yaw_rate_des, (const R*)nullptr, torque_out, out_flags);
+}
+
 // GeometricController.compute_control (controller.py:413-512) for one drone.
 template <typename R>
 __device__ void control_step(const CtrlDev<R>& c, CtrlRegs<R>& s, double t, const R pos[3], const R vel[3], const R att[3],
@@ -151,33 +273,7 @@ __device__ void control_step(const CtrlDev<R>& c, CtrlRegs<R>& s, double t, cons
   else if (tm < c.min_thrust_abs) { tm = c.min_thrust_abs; thrust_sat = true; }
   s.flags = (s.flags & ~2) | (thrust_sat ? 2 : 0);                               // :477
   if (thrust_sat) out_flags |= CF_THRUST_SAT;
-  // ---- _update_integral_error (:548-578); the torque saturation flags are still the previous call's
-  {
-    R upd[3];
-    for (int i = 0; i < 3; ++i) upd[i] = ve[i] * dt;
-    if (c.anti_windup == 0) {                                                    // clamping (:580-598)
-      if (thrust_sat) for (int i = 0; i < 3; ++i) upd[i] = upd[i] * (R)0.1;
-      for (int i = 0; i < 3; ++i) if (s.flags & (4 << i)) upd[i] = upd[i] * (R)0.1;
-    } else if (c.anti_windup == 1) {                                             // back-calculation (:600-623)
-      if (thrust_sat) {
-        const R fb = (s.unsat_thrust - c.max_thrust) * c.kb;
-        upd[0] = upd[0] - fb * (R)0.33; upd[1] = upd[1] - fb * (R)0.33; upd[2] = upd[2] - fb * (R)0.34;
-      }
-      for (int i = 0; i < 3; ++i)
-        if (s.flags & (4 << i)) upd[i] = upd[i] - ((s.unsat_torque[i] - c.max_torque[i]) * c.kb) * (R)0.5;
-    }
-    R I[3];
-    for (int i = 0; i < 3; ++i) {
-      I[i] = s.integral[i] + upd[i];                                             // :574
-      if (fabs(I[i]) > c.max_int_axis[i]) I[i] = sign_of(I[i]) * c.max_int_axis[i];   // :630-632
-    }
-    const R mag = norm3(I);
-    if (mag > c.max_integral_pos) { const R f = c.max_integral_pos / mag; for (int i = 0; i < 3; ++i) I[i] = I[i] * f; }   // :635-637
-    for (int i = 0; i < 3; ++i) {
-      if (fabs(I[i]) > c.max_int_axis[i] * c.sat_thr) I[i] = I[i] * c.decay;     // :640-643
-      s.integral[i] = I[i];
-    }
-  }
+  update_integral(c, s, ve, dt, thrust_sat);                                     // :480
   // ---- _check_tracking_performance (:650-658)
   if (pen > c.track_thr && ven > c.vel_thr) s.failsafe_count += 1;
   else s.failsafe_count = s.failsafe_count > 1 ? s.failsafe_count - 1 : 0;
@@ -187,73 +283,50 @@ __device__ void control_step(const CtrlDev<R>& c, CtrlRegs<R>& s, double t, cons
     out_flags |= CF_FAILSAFE;
     return;
   }
-  // ---- desired thrust direction (:487-496): divided by the SATURATED magnitude, then the tilt limit
-  R b3[3];
-  if (tm > (R)1e-6) { b3[0] = tvw[0] / tm; b3[1] = tvw[1] / tm; b3[2] = tvw[2] / tm; }
-  else { b3[0] = (R)0; b3[1] = (R)0; b3[2] = (R)1; }
-  const R tilt = acos(fmin(fmax(b3[2], (R)-1), (R)1));
-  if (tilt > c.max_tilt) {
-    const R sf = c.cos_max_tilt / b3[2];
-    b3[0] = b3[0] * sf; b3[1] = b3[1] * sf; b3[2] = c.cos_max_tilt;
-    const R n = norm3(b3);
-    b3[0] = b3[0] / n; b3[1] = b3[1] / n; b3[2] = b3[2] / n;
-    out_flags |= CF_TILT;
-  }
-  // ---- _geometric_attitude_control (:660-715)
-  const R cr = cos(att[0]), sr = sin(att[0]), cp = cos(att[1]), sp = sin(att[1]), cy = cos(att[2]), sy = sin(att[2]);
-  const R Rm[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},   // :774-789
-                      {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
-                      {-sp, cp * sr, cp * cr}};
-  const R yv[3] = {cos(yaw_des), sin(yaw_des), (R)0};                             // :665
-  const R n3 = norm3(b3);
-  const R b3n[3] = {b3[0] / n3, b3[1] / n3, b3[2] / n3};                          // :667
-  const R cos_angle = fabs(yv[0] * b3n[0] + yv[1] * b3n[1] + yv[2] * b3n[2]);     // :174
-  R b1[3], b2[3];
-  if (cos_angle >= c.yaw_sing_thr) {                                              // :177, :191-257
-    out_flags |= CF_SINGULAR;
-    R proj[3] = {(R)1 - b3n[0] * b3n[0], (R)0 - b3n[0] * b3n[1], (R)0 - b3n[0] * b3n[2]};   // [1,0,0] - ([1,0,0].b3) b3
-    const R np_ = norm3(proj);
-    proj[0] = proj[0] / np_; proj[1] = proj[1] / np_; proj[2] = proj[2] / np_;
-    if (c.fallback == 1 || c.fallback == 2) {                                     // default_heading / maintain_current
-      const R hv[3] = {c.fallback == 1 ? c.dh_cos : cy, c.fallback == 1 ? c.dh_sin : sy, (R)0};
-      R cx[3];
-      cross3(hv, b3n, cx);
-      const R nc = norm3(cx);
-      if (nc > (R)1e-6) { b1[0] = cx[0] / nc; b1[1] = cx[1] / nc; b1[2] = cx[2] / nc; }
-      else { b1[0] = proj[0]; b1[1] = proj[1]; b1[2] = proj[2]; }
-    } else if (c.fallback != 0 || fabs(b3n[2]) < (R)0.99) {                       // skip_yaw (:212-217); unknown methods (:248-252)
-      b1[0] = proj[0]; b1[1] = proj[1]; b1[2] = proj[2];
-    } else {                                                                      // :218-220
-      b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0;
-    }
-  } else {                                                                        // :680-688
-    cross3(yv, b3n, b1);
-    const R n1 = norm3(b1);
-    if (n1 > (R)1e-6) { b1[0] = b1[0] / n1; b1[1] = b1[1] / n1; b1[2] = b1[2] / n1; }
-    else { b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0; }
-  }
-  cross3(b3n, b1, b2);                                                            // :255 / :689
-  const R Rd[3][3] = {{b1[0], b2[0], b3n[0]}, {b1[1], b2[1], b3n[1]}, {b1[2], b2[2], b3n[2]}};   // column_stack
-  // eR = 0.5 vee(Rd^T R - R^T Rd) (:692): vee(M) = (M21, M02, M10)
-  auto dtr = [&](const R A_[3][3], const R B_[3][3], int i, int j) { return (A_[0][i] * B_[0][j] + A_[1][i] * B_[1][j]) + A_[2][i] * B_[2][j]; };
-  const R eR[3] = {(R)0.5 * (dtr(Rd, Rm, 2, 1) - dtr(Rm, Rd, 2, 1)), (R)0.5 * (dtr(Rd, Rm, 0, 2) - dtr(Rm, Rd, 0, 2)),
-                   (R)0.5 * (dtr(Rd, Rm, 1, 0) - dtr(Rm, Rd, 1, 0))};
-  const R eO[3] = {omega[0], omega[1], omega[2] - yaw_rate_des};                  // :693-695
-  const R Iw[3] = {c.inertia[0] * omega[0], c.inertia[1] * omega[1], c.inertia[2] * omega[2]};
-  R cor[3];
-  cross3(omega, Iw, cor);                                                         // :700
-  int tsat = 0;
-  for (int i = 0; i < 3; ++i) {
-    R tq = (-(c.kp_att[i] * scale) * eR[i] - (c.kd_att[i] * scale) * eO[i]) + cor[i];   // :701
-    s.unsat_torque[i] = tq;                                                       // :704
-    if (fabs(tq) > c.max_torque[i]) { tq = sign_of(tq) * c.max_torque[i]; tsat |= (4 << i); }   // :708-711
-    torque_out[i] = tq;
-  }
-  s.flags = (s.flags & ~(4 | 8 | 16)) | tsat;                                     // :713
-  out_flags |= (tsat >> 2) * CF_TORQUE_SAT_X;
+  attitude_command(c, s, scale, tvw, tm, att, omega, yaw_des, yaw_rate_des, torque_out, out_flags);   // :487-504
   s.last_valid_thrust = tm;                                                       // :505
   s.flags &= ~1;                                                                  // :506
   s.failsafe_count = 0;                                                           // :507
+  thrust_out = tm;
+}
+
+// GeometricController.compute_control_fast (controller.py:253-346; compute_control_from_fast_state, :728-768, forwards to it) for one
+// drone: the unit-free path of the reference's 400 Hz hardware loop (hardware/pixhawk_interface.py:401).  dt is an argument; an invalid
+// one returns the VEHICLE's hover thrust and touches nothing (:279-280); gravity and the lower thrust limit come from the vehicle
+// constants (common/vehicle_params.py:19-23 via :118-127), not the controller config; no tracking check, and last_time /
+// last_valid_thrust / failsafe_active / failsafe_count stay as they are (gains halved by a compute_control failsafe stay halved).
+template <typename R>
+struct FastDev {
+  R gravity, min_thrust_abs, hover;
+};
+template <typename R>
+__device__ void control_step_fast(const CtrlDev<R>& c, const FastDev<R>& f, CtrlRegs<R>& s, double dt_d, const R pos[3], const R vel[3],
+                                  const R att[3], const R omega[3], const R dpos[3], const R dvel[3], const R dacc[3], R yaw_des,
+                                  R yaw_rate_des, R& thrust_out, R torque_out[3], int& out_flags) {
+  out_flags = 0;
+  if (dt_d <= 0.0 || dt_d > 0.1) {                                               // :279-280
+    thrust_out = f.hover; torque_out[0] = torque_out[1] = torque_out[2] = (R)0;
+    out_flags = CF_BAD_DT;
+    return;
+  }
+  const R dt = (R)dt_d;
+  const R scale = (R)ldexp(1.0, -s.halvings);
+  R pe[3], ve[3], tvw[3];
+  for (int i = 0; i < 3; ++i) { pe[i] = dpos[i] - pos[i]; ve[i] = dvel[i] - vel[i]; }   // :283-284
+  for (int i = 0; i < 3; ++i) {
+    const R acc_pid = ((c.kp_pos[i] * scale) * pe[i] + (c.kd_pos[i] * scale) * ve[i]) + c.ki_pos[i] * s.integral[i];   // :293-297
+    tvw[i] = dacc[i] + acc_pid;                                                  // :298
+  }
+  tvw[2] = tvw[2] + f.gravity;                                                   // :301
+  R tm = norm3(tvw);                                                             // :302
+  s.unsat_thrust = tm;                                                           // :305
+  bool thrust_sat = false;
+  if (tm > c.max_thrust) { tm = c.max_thrust; thrust_sat = true; }               // :312-320 (the caller counts the saturations from the flags)
+  else if (tm < f.min_thrust_abs) { tm = f.min_thrust_abs; thrust_sat = true; }
+  s.flags = (s.flags & ~2) | (thrust_sat ? 2 : 0);                               // :322
+  if (thrust_sat) out_flags |= CF_THRUST_SAT;
+  update_integral(c, s, ve, dt, thrust_sat);                                     // :325
+  attitude_command(c, s, scale, tvw, tm, att, omega, yaw_des, yaw_rate_des, torque_out, out_flags);   // :328-344
   thrust_out = tm;
 }
 
@@ -353,6 +426,91 @@ control_kernel(CtrlDev<R> c, int B, const double* __restrict__ time, const R* __
     for (int i = 0; i < 3; ++i) body_rates[3 * b + i] = w[i] + (tq[i] / inr[i]) * (R)0.001;   // :718-720
   }
   if (flags != nullptr) flags[b] = fl;
+}
+
+// ---- one compute_control_fast call per drone
+template <typename R>
+__global__ void __launch_bounds__(64)
+control_fast_kernel(CtrlDev<R> c, FastDev<R> f, int B, double dt, const R* __restrict__ pos, const R* __restrict__ vel,
+                    const R* __restrict__ att, const R* __restrict__ omega, const R* __restrict__ dpos, const R* __restrict__ dvel,
+                    const R* __restrict__ dacc, const R* __restrict__ yaw, const R* __restrict__ yaw_rate, double* __restrict__ state,
+                    R* __restrict__ thrust, R* __restrict__ torque, int32_t* __restrict__ flags) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  CtrlRegs<R> s = load_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS);
+  R p[3], v[3], a[3], w[3], dp[3], dv[3], da[3];
+  for (int i = 0; i < 3; ++i) {
+    p[i] = pos[3 * b + i]; v[i] = vel[3 * b + i]; a[i] = att[3 * b + i]; w[i] = omega[3 * b + i];
+    dp[i] = dpos[3 * b + i]; dv[i] = dvel[3 * b + i]; da[i] = dacc != nullptr ? dacc[3 * b + i] : (R)0;
+  }
+  R th, tq[3];
+  int fl;
+  control_step_fast<R>(c, f, s, dt, p, v, a, w, dp, dv, da, yaw != nullptr ? yaw[b] : (R)0, yaw_rate != nullptr ? yaw_rate[b] : (R)0, th, tq, fl);
+  store_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS, s);
+  if (thrust != nullptr) thrust[b] = th;
+  if (torque != nullptr) for (int i = 0; i < 3; ++i) torque[3 * b + i] = tq[i];
+  if (flags != nullptr) flags[b] = fl;
+}
+
+// ---- the controller's building blocks, one call per drone: what the reference's own controller tests call directly
+// (tests/control/test_geometric_controller_anti_windup.py, test_geometric_controller_yaw_singularity.py, tests/test_controller_torque_calculation.py)
+template <typename R>
+struct Inertia9 {
+  R m[9];
+  int use;
+};
+
+// _update_integral_error(vel_error, dt, thrust_saturated, torque_saturated) (controller.py:536-564): the saturation flags are ARGUMENTS
+// (sat bit 0 thrust, bits 1..3 torque x/y/z; null = none), the unsaturated thrust / torques are read from the record.
+template <typename R>
+__global__ void __launch_bounds__(64)
+integral_update_kernel(CtrlDev<R> c, int B, const R* __restrict__ vel_error, double dt, const int32_t* __restrict__ sat, double* __restrict__ state) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  CtrlRegs<R> s = load_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS);
+  const int keep = s.flags, sb = sat != nullptr ? sat[b] : 0;
+  s.flags = (s.flags & ~(4 | 8 | 16)) | (((sb >> 1) & 7) << 2);
+  const R ve[3] = {vel_error[3 * b], vel_error[3 * b + 1], vel_error[3 * b + 2]};
+  update_integral(c, s, ve, (R)dt, (sb & 1) != 0);
+  s.flags = keep;
+  store_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS, s);
+}
+
+// _geometric_attitude_control / _fast_geometric_attitude_control(att, ang_vel, b3_des, yaw_des, yaw_rate_des) (:643-704, :348-411)
+template <typename R>
+__global__ void __launch_bounds__(64)
+attitude_torque_kernel(CtrlDev<R> c, Inertia9<R> I, int B, const R* __restrict__ att, const R* __restrict__ omega, const R* __restrict__ b3_des,
+                       const R* __restrict__ yaw, const R* __restrict__ yaw_rate, double* __restrict__ state, R* __restrict__ torque,
+                       int32_t* __restrict__ flags) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  CtrlRegs<R> s = load_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS);
+  R a[3], w[3], b3[3], tq[3];
+  for (int i = 0; i < 3; ++i) { a[i] = att[3 * b + i]; w[i] = omega[3 * b + i]; b3[i] = b3_des[3 * b + i]; }
+  int fl = 0;
+  attitude_torque<R>(c, s, (R)ldexp(1.0, -s.halvings), b3, a, w, yaw != nullptr ? yaw[b] : (R)0, yaw_rate != nullptr ? yaw_rate[b] : (R)0,
+                     I.use ? I.m : (const R*)nullptr, tq, fl);
+  store_ctrl<R>(state + (size_t)b * SE3MPC_CONTROLLER_STATE_WORDS, s);
+  if (torque != nullptr) for (int i = 0; i < 3; ++i) torque[3 * b + i] = tq[i];
+  if (flags != nullptr) flags[b] = fl;
+}
+
+// _detect_yaw_singularity(yaw_vector, b3_des) (:160-189) and the frame: method < 0 -> what _geometric_attitude_control builds (the configured
+// fallback only when singular); method >= 0 -> _handle_yaw_singularity(yaw_vector, b3_des, current_yaw, method) (:191-252) whatever cos_angle says.
+template <typename R>
+__global__ void __launch_bounds__(64)
+desired_frame_kernel(CtrlDev<R> c, int B, int method, const R* __restrict__ yaw_vector, const R* __restrict__ b3_des, const R* __restrict__ current_yaw,
+                     R* __restrict__ frame, R* __restrict__ cos_angle, int32_t* __restrict__ singular) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  R yv[3], b3[3], b1[3], b2[3], ca;
+  for (int i = 0; i < 3; ++i) { yv[i] = yaw_vector[3 * b + i]; b3[i] = b3_des[3 * b + i]; }
+  const R cyaw = current_yaw != nullptr ? current_yaw[b] : (R)0;
+  bool sing;
+  desired_frame<R>(c, method < 0 ? c.fallback : method, method >= 0, yv, b3, cos(cyaw), sin(cyaw), b1, b2, ca, sing);
+  if (frame != nullptr) for (int i = 0; i < 3; ++i) { frame[9 * b + i] = b1[i]; frame[9 * b + 3 + i] = b2[i]; frame[9 * b + 6 + i] = b3[i]; }
+  if (cos_angle != nullptr) cos_angle[b] = ca;
+  if (singular != nullptr) singular[b] = sing ? 1 : 0;
 }
 
 // ---- the closed loop: nsteps x (sample, control, simulate) per drone in one launch
@@ -468,6 +626,71 @@ int control_impl(const se3mpc_controller_params* cp, int B, const double* time, 
 }
 
 template <typename R>
+int control_fast_impl(const se3mpc_controller_params* cp, double vehicle_mass, double vehicle_gravity, int B, double dt, const R* pos,
+                      const R* vel, const R* att, const R* omega, const R* dpos, const R* dvel, const R* dacc, const R* yaw,
+                      const R* yaw_rate, double* state, R* thrust, R* torque, int32_t* flags, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  if (!std::isfinite(vehicle_mass) || !std::isfinite(vehicle_gravity) || !(vehicle_mass > 0.0) || dt != dt) return SE3MPC_ERR_PARAM;
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!pos || !vel || !att || !omega || !dpos || !dvel || !state) return SE3MPC_ERR_NULL;
+  FastDev<R> f;
+  f.gravity = (R)vehicle_gravity;
+  f.min_thrust_abs = (R)(cp->min_thrust * vehicle_mass * vehicle_gravity);       // controller.py:127
+  f.hover = (R)(vehicle_mass * vehicle_gravity);                                  // :280
+  hipLaunchKernelGGL(control_fast_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), f, B, dt, pos, vel,
+                     att, omega, dpos, dvel, dacc, yaw, yaw_rate, state, thrust, torque, flags);
+  return launch_status("se3mpc_control_fast");
+}
+
+template <typename R>
+int integral_update_impl(const se3mpc_controller_params* cp, int B, const R* vel_error, double dt, const int32_t* saturation, double* state,
+                         void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  if (dt != dt) return SE3MPC_ERR_PARAM;
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!vel_error || !state) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(integral_update_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), B, vel_error, dt,
+                     saturation, state);
+  return launch_status("se3mpc_controller_integral_update");
+}
+
+template <typename R>
+int attitude_torque_impl(const se3mpc_controller_params* cp, int B, const R* att, const R* omega, const R* b3_des, const R* yaw,
+                         const R* yaw_rate, const double* inertia, double* state, R* torque, int32_t* flags, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  Inertia9<R> I;
+  I.use = inertia != nullptr;
+  for (int i = 0; i < 9; ++i) {
+    if (inertia != nullptr && !std::isfinite(inertia[i])) return SE3MPC_ERR_PARAM;
+    I.m[i] = inertia != nullptr ? (R)inertia[i] : (R)0;
+  }
+  if (B < 0) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!att || !omega || !b3_des || !state) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(attitude_torque_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), I, B, att, omega,
+                     b3_des, yaw, yaw_rate, state, torque, flags);
+  return launch_status("se3mpc_controller_attitude_torque");
+}
+
+template <typename R>
+int desired_frame_impl(const se3mpc_controller_params* cp, int B, int method, const R* yaw_vector, const R* b3_des, const R* current_yaw,
+                       R* frame, R* cos_angle, int32_t* singular, void* stream) {
+  int rc = check_controller_params(cp);
+  if (rc) return rc;
+  if (B < 0 || method > 3) return SE3MPC_ERR_SHAPE;
+  if (B == 0) return SE3MPC_OK;
+  if (!yaw_vector || !b3_des) return SE3MPC_ERR_NULL;
+  hipLaunchKernelGGL(desired_frame_kernel<R>, dim3(grid_for(B, 64)), dim3(64), 0, (hipStream_t)stream, make_ctrl_dev<R>(*cp), B, method, yaw_vector,
+                     b3_des, current_yaw, frame, cos_angle, singular);
+  return launch_status("se3mpc_controller_desired_frame");
+}
+
+template <typename R>
 int control_plan_impl(const se3mpc_controller_params* cp, int B, const double* time, const double* sample_time, const R* pos, const R* vel,
                       const R* att, const R* omega, int N, const double* timestamps, long long ts_stride, const R* P, long long strideP,
                       const R* V, long long strideV, const R* A, long long strideA, double* state, R* thrust, R* torque, R* body_thrust,
@@ -566,6 +789,27 @@ extern "C" int se3mpc_controller_reset(const se3mpc_controller_params* cp, int B
                                       int32_t* flags, void* stream) {                                                       \
     return control_impl<R>(cp, B, time, pos, vel, att, omega, dpos, dvel, dacc, yaw, yaw_rate, state, thrust, torque,       \
                            body_thrust, body_rates, flags, stream);                                                        \
+  }                                                                                                                         \
+  extern "C" int se3mpc_control_fast_##SUF(const se3mpc_controller_params* cp, double vehicle_mass, double vehicle_gravity, int B,  \
+                                           double dt, const R* pos, const R* vel, const R* att, const R* omega, const R* dpos,   \
+                                           const R* dvel, const R* dacc, const R* yaw, const R* yaw_rate, double* state, R* thrust, \
+                                           R* torque, int32_t* flags, void* stream) {                                          \
+    return control_fast_impl<R>(cp, vehicle_mass, vehicle_gravity, B, dt, pos, vel, att, omega, dpos, dvel, dacc, yaw, yaw_rate, \
+                                state, thrust, torque, flags, stream);                                                      \
+  }                                                                                                                         \
+  extern "C" int se3mpc_controller_integral_update_##SUF(const se3mpc_controller_params* cp, int B, const R* vel_error, double dt,   \
+                                                         const int32_t* saturation, double* state, void* stream) {             \
+    return integral_update_impl<R>(cp, B, vel_error, dt, saturation, state, stream);                                        \
+  }                                                                                                                         \
+  extern "C" int se3mpc_controller_attitude_torque_##SUF(const se3mpc_controller_params* cp, int B, const R* att, const R* omega,   \
+                                                         const R* b3_des, const R* yaw, const R* yaw_rate, const double* inertia, \
+                                                         double* state, R* torque, int32_t* flags, void* stream) {           \
+    return attitude_torque_impl<R>(cp, B, att, omega, b3_des, yaw, yaw_rate, inertia, state, torque, flags, stream);          \
+  }                                                                                                                         \
+  extern "C" int se3mpc_controller_desired_frame_##SUF(const se3mpc_controller_params* cp, int B, int method, const R* yaw_vector,  \
+                                                       const R* b3_des, const R* current_yaw, R* frame, R* cos_angle,        \
+                                                       int32_t* singular, void* stream) {                                   \
+    return desired_frame_impl<R>(cp, B, method, yaw_vector, b3_des, current_yaw, frame, cos_angle, singular, stream);         \
   }                                                                                                                         \
   extern "C" int se3mpc_control_plan_##SUF(const se3mpc_controller_params* cp, int B, const double* time, const double* sample_time, \
                                            const R* pos, const R* vel, const R* att, const R* omega, int N, const double* timestamps, \

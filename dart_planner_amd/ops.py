@@ -13,9 +13,9 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
-import numpy as np
-
 import ctypes as _C
+
+import numpy as np
 
 from .capi import (CONTROLLER_STATE_WORDS, ControllerParams, Library, Params, SimulatorParams, SolveInfo, get_library,
                    SE3MPC_MAX_SPHERES)
@@ -446,6 +446,82 @@ class Ops:
         if want_body_rate:
             out.update(body_thrust=bt, body_rates=br)
         return out
+
+    def control_fast(self, cp: ControllerParams, state, dt: float, pos, vel, att, omega, dpos, dvel, dacc=None, yaw=None, yaw_rate=None,
+                     vehicle_mass: float = 1.0, vehicle_gravity: float = 9.80665):
+        """compute_control_fast / compute_control_from_fast_state (controller.py:253-411, :728-768) for B drones: dt in seconds is given;
+        vehicle_mass / vehicle_gravity = get_control_constants() (common/vehicle_params.py:19-23 by default).  `state` (B, 12) float64
+        is the record se3mpc_control_* uses, updated in place.  -> dict(thrust (B,), torque (B,3), flags int32 (B,))."""
+        B = pos.shape[0]
+        suf = self.be.suffix(pos)
+        for a, nm in ((pos, "pos"), (vel, "vel"), (att, "att"), (omega, "omega"), (dpos, "dpos"), (dvel, "dvel")):
+            self._rows3(a, B, nm, suf)
+        if dacc is not None:
+            self._rows3(dacc, B, "dacc", suf)
+        for a, nm in ((yaw, "yaw"), (yaw_rate, "yaw_rate")):
+            if a is not None:
+                self.be.check(a, nm)
+                if tuple(a.shape) != (B,) or self.be.suffix(a) != suf:
+                    raise ValueError(f"{nm}: expected ({B},) {suf}")
+        self.be.check(state, "state")
+        if tuple(state.shape) != (B, CONTROLLER_STATE_WORDS) or self.be.suffix(state) != "f64":
+            raise ValueError("state: float64 (B, 12)")
+        thrust, torque = self.be.empty((B,), suf), self.be.empty((B, 3), suf)
+        flags = self.be.empty((B,), "i32")
+        self.lib.loop_call("control_fast", suf, cp, float(vehicle_mass), float(vehicle_gravity), B, float(dt), self.be.ptr(pos), self.be.ptr(vel),
+                           self.be.ptr(att), self.be.ptr(omega), self.be.ptr(dpos), self.be.ptr(dvel), self.be.ptr(dacc), self.be.ptr(yaw),
+                           self.be.ptr(yaw_rate), self.be.ptr(state), self.be.ptr(thrust), self.be.ptr(torque), self.be.ptr(flags),
+                           self.be.stream())
+        return dict(thrust=thrust, torque=torque, flags=flags)
+
+    def controller_integral_update(self, cp: ControllerParams, state, vel_error, dt: float, saturation=None) -> None:
+        """_update_integral_error(vel_error, dt, thrust_saturated, torque_saturated) (controller.py:536-564) for B drones, in place on
+        `state`.  saturation: int32 (B,) bit 0 thrust, bits 1..3 torque x/y/z, or None."""
+        B = vel_error.shape[0]
+        suf = self.be.suffix(vel_error)
+        self._rows3(vel_error, B, "vel_error", suf)
+        self.be.check(state, "state")
+        if tuple(state.shape) != (B, CONTROLLER_STATE_WORDS) or self.be.suffix(state) != "f64":
+            raise ValueError("state: float64 (B, 12)")
+        if saturation is not None:
+            self.be.check(saturation, "saturation")
+            if tuple(saturation.shape) != (B,) or saturation.element_size() != 4 if hasattr(saturation, "element_size") else saturation.itemsize != 4:
+                raise ValueError("saturation: int32 (B,)")
+        self.lib.loop_call("controller_integral_update", suf, cp, B, self.be.ptr(vel_error), float(dt), self.be.ptr(saturation), self.be.ptr(state),
+                           self.be.stream())
+
+    def controller_attitude_torque(self, cp: ControllerParams, state, att, omega, b3_des, yaw=None, yaw_rate=None, inertia=None):
+        """_geometric_attitude_control / _fast_geometric_attitude_control (controller.py:643-704, :348-411) for B drones.
+        inertia: None (diag of cp.inertia) or a host 3x3.  -> dict(torque (B,3), flags int32 (B,)); `state` takes the unsaturated torques
+        and the torque saturation flags."""
+        B = att.shape[0]
+        suf = self.be.suffix(att)
+        for a, nm in ((att, "att"), (omega, "omega"), (b3_des, "b3_des")):
+            self._rows3(a, B, nm, suf)
+        self.be.check(state, "state")
+        if tuple(state.shape) != (B, CONTROLLER_STATE_WORDS) or self.be.suffix(state) != "f64":
+            raise ValueError("state: float64 (B, 12)")
+        mat = None
+        if inertia is not None:
+            m = np.asarray(inertia, dtype=np.float64)
+            if m.shape != (3, 3):
+                raise ValueError("inertia: a 3x3 matrix")
+            mat = (_C.c_double * 9)(*m.reshape(-1))
+        torque, flags = self.be.empty((B, 3), suf), self.be.empty((B,), "i32")
+        self.lib.loop_call("controller_attitude_torque", suf, cp, B, self.be.ptr(att), self.be.ptr(omega), self.be.ptr(b3_des), self.be.ptr(yaw),
+                           self.be.ptr(yaw_rate), mat, self.be.ptr(state), self.be.ptr(torque), self.be.ptr(flags), self.be.stream())
+        return dict(torque=torque, flags=flags)
+
+    def controller_desired_frame(self, cp: ControllerParams, yaw_vector, b3_des, current_yaw=None, method: int = -1):
+        """_detect_yaw_singularity (controller.py:160-189) + the desired frame: method -1 = as _geometric_attitude_control builds it,
+        0..3 = _handle_yaw_singularity with that fallback (:191-252).  -> dict(frame (B,9) = b1|b2|b3, cos_angle (B,), singular int32 (B,))."""
+        B = yaw_vector.shape[0]
+        suf = self.be.suffix(yaw_vector)
+        self._rows3(yaw_vector, B, "yaw_vector", suf); self._rows3(b3_des, B, "b3_des", suf)
+        frame, ca, sg = self.be.empty((B, 9), suf), self.be.empty((B,), suf), self.be.empty((B,), "i32")
+        self.lib.loop_call("controller_desired_frame", suf, cp, B, int(method), self.be.ptr(yaw_vector), self.be.ptr(b3_des), self.be.ptr(current_yaw),
+                           self.be.ptr(frame), self.be.ptr(ca), self.be.ptr(sg), self.be.stream())
+        return dict(frame=frame, cos_angle=ca, singular=sg)
 
     def _plan_args(self, B, suf, timestamps, P, V, A, strides):
         self.be.check(timestamps, "timestamps")

@@ -434,6 +434,51 @@ int se3mpc_control_f64(const se3mpc_controller_params* cp, int B, const double* 
                        const double* yaw, const double* yaw_rate, double* state, double* thrust, double* torque, double* body_thrust,
                        double* body_rates, int32_t* flags, void* stream);
 
+/* compute_control_fast / compute_control_from_fast_state (controller.py:253-411, :728-768), the unit-free path of the reference's
+ * 400 Hz hardware loop (hardware/pixhawk_interface.py:401), for B drones: dt (seconds) is an argument; an invalid one (dt <= 0 or
+ * dt > 0.1) returns vehicle_mass * vehicle_gravity and zero torque and changes nothing (flag bit 1; no failsafe).  Gravity and the
+ * lower thrust limit (min_thrust * vehicle_mass * vehicle_gravity) come from the vehicle constants (common/vehicle_params.py:19-23:
+ * 1.0 kg, 9.80665 m/s^2), not from cp->mass / cp->gravity.  Same `state` record as se3mpc_control_* (the two paths share integral,
+ * halved gains and saturation flags); last_time, last_valid_thrust, failsafe_active and failsafe_count are not written.  flags as
+ * se3mpc_control_* (bits 2, 5..7 are what the reference adds to its _thrust_saturation_count / _torque_saturation_count). */
+int se3mpc_control_fast_f32(const se3mpc_controller_params* cp, double vehicle_mass, double vehicle_gravity, int B, double dt,
+                            const float* pos, const float* vel, const float* att, const float* omega, const float* dpos,
+                            const float* dvel, const float* dacc, const float* yaw, const float* yaw_rate, double* state, float* thrust,
+                            float* torque, int32_t* flags, void* stream);
+int se3mpc_control_fast_f64(const se3mpc_controller_params* cp, double vehicle_mass, double vehicle_gravity, int B, double dt,
+                            const double* pos, const double* vel, const double* att, const double* omega, const double* dpos,
+                            const double* dvel, const double* dacc, const double* yaw, const double* yaw_rate, double* state,
+                            double* thrust, double* torque, int32_t* flags, void* stream);
+
+/* The controller's building blocks, as the reference's own controller tests call them (tests/control/
+ * test_geometric_controller_anti_windup.py, test_geometric_controller_yaw_singularity.py, tests/test_controller_torque_calculation.py),
+ * for B drones on the same `state` record:
+ *  - integral_update = _update_integral_error(vel_error, dt, thrust_saturated, torque_saturated) (controller.py:536-564) with its
+ *    anti-windup method and _clamp_integral_per_axis: vel_error [B][3]; saturation int32 [B] (bit 0 thrust, bits 1..3 torque x/y/z;
+ *    NULL = none); the unsaturated thrust / torques of the back-calculation are read from the record;
+ *  - attitude_torque = _geometric_attitude_control / _fast_geometric_attitude_control(att, ang_vel, b3_des, yaw_des, yaw_rate_des)
+ *    (:643-704, :348-411): torque [B][3], flags as se3mpc_control_* (bits 3, 5..7); writes the record's unsaturated torques and torque
+ *    saturation flags.  inertia: NULL = diag(cp->inertia), or host double[9] row-major (the tests assign a full matrix to _fast_inertia);
+ *  - desired_frame = _detect_yaw_singularity(yaw_vector, b3_des) (:160-189) -> cos_angle [B], singular int32 [B], and frame [B][9] =
+ *    (b1, b2, b3): method < 0 what _geometric_attitude_control builds (cp's fallback only when singular); method 0..3 =
+ *    _handle_yaw_singularity(yaw_vector, b3_des, current_yaw, method) (:191-252) unconditionally.  Any output may be NULL. */
+int se3mpc_controller_integral_update_f32(const se3mpc_controller_params* cp, int B, const float* vel_error, double dt,
+                                          const int32_t* saturation, double* state, void* stream);
+int se3mpc_controller_integral_update_f64(const se3mpc_controller_params* cp, int B, const double* vel_error, double dt,
+                                          const int32_t* saturation, double* state, void* stream);
+int se3mpc_controller_attitude_torque_f32(const se3mpc_controller_params* cp, int B, const float* att, const float* omega,
+                                          const float* b3_des, const float* yaw, const float* yaw_rate, const double* inertia,
+                                          double* state, float* torque, int32_t* flags, void* stream);
+int se3mpc_controller_attitude_torque_f64(const se3mpc_controller_params* cp, int B, const double* att, const double* omega,
+                                          const double* b3_des, const double* yaw, const double* yaw_rate, const double* inertia,
+                                          double* state, double* torque, int32_t* flags, void* stream);
+int se3mpc_controller_desired_frame_f32(const se3mpc_controller_params* cp, int B, int method, const float* yaw_vector,
+                                        const float* b3_des, const float* current_yaw, float* frame, float* cos_angle,
+                                        int32_t* singular, void* stream);
+int se3mpc_controller_desired_frame_f64(const se3mpc_controller_params* cp, int B, int method, const double* yaw_vector,
+                                        const double* b3_des, const double* current_yaw, double* frame, double* cos_angle,
+                                        int32_t* singular, void* stream);
+
 /* compute_control_from_trajectory(state, trajectory, t) / compute_body_rate_from_trajectory -- stubs in the reference
  * (controller.py:873-875; the second does not exist), the glue its contract test calls: target = the plan sampled at sample_time[b]
  * with OnboardController._interpolate_trajectory (onboard.py:43-93), then compute_control(state, target, yaw 0, yaw rate 0).

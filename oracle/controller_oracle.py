@@ -7,6 +7,8 @@ A float64 NumPy restatement, batched over a leading drone axis, of
   ``_check_tracking_performance``, ``_geometric_attitude_control``, the yaw-singularity detection and its three
   fallbacks, ``_get_failsafe_command``) -- /root/reference/src/dart_planner/control/geometric_controller.py
   ("controller.py" below), gains from control_config.py:95-111 (profile "sitl_optimized");
+* ``compute_control_fast`` / ``compute_control_from_fast_state`` (controller.py:253-411, :728-768), the unit-free variant the
+  reference's 400 Hz hardware loop calls (hardware/pixhawk_interface.py:401);
 * ``DroneSimulator.step`` -- /root/reference/src/dart_planner/utils/drone_simulator.py:52-72 ("simulator.py");
 * ``OnboardController._interpolate_trajectory`` -- /root/reference/src/dart_planner/control/onboard_controller.py:43-93
   ("onboard.py"), the reference's own plan sampler, which is what the glue
@@ -248,6 +250,70 @@ def compute_control(st: ControllerState, cfg: ControllerConfig, t, pos, vel, att
     torque = np.where(fs[:, None], 0.0, torque)
     return thrust, torque, dict(failsafe=fs, bad_dt=bad_dt, thrust_saturated=thrust_sat & ok, singular=singular & run,
                                 tilt_limited=over & run, dt=dt)
+
+
+@dataclass
+class VehicleConstants:
+    """``get_control_constants()`` (common/vehicle_params.py:68-77 over the ``VehicleParams`` defaults, :19-23): the mass and gravity
+    the FAST path uses (controller.py:118-127) -- not the controller config's."""
+    mass: float = 1.0
+    gravity: float = 9.80665
+
+
+def compute_control_fast(st: ControllerState, cfg: ControllerConfig, veh: VehicleConstants, dt, pos, vel, att, omega, dpos, dvel, dacc,
+                         yaw_des=None, yaw_rate_des=None) -> Tuple[np.ndarray, np.ndarray, Dict[str, np.ndarray]]:
+    """GeometricController.compute_control_fast (controller.py:253-346) with _fast_geometric_attitude_control (:348-411) -- what
+    compute_control_from_fast_state (:728-768) forwards to, the unit-free path of the reference's 400 Hz loop
+    (hardware/pixhawk_interface.py:401) -- for B drones at once; mutates ``st``.  dt: scalar or (B,).  Against compute_control: dt is an
+    argument and an invalid one returns the vehicle's hover thrust with NO failsafe and no state change (:279-280); gravity and the lower
+    thrust limit come from the vehicle constants (:303, :317, :127); no tracking check; last_time / last_valid_thrust / failsafe_active /
+    failsafe_count are not touched (the gains stay halved if compute_control halved them).  -> thrust (B,), torque (B,3), flags (the
+    reference counts the saturations it reports here, :315-320, :404)."""
+    B = len(pos)
+    dt = np.broadcast_to(np.asarray(dt, float), (B,))
+    yaw_des = np.zeros(B) if yaw_des is None else np.asarray(yaw_des, float)
+    yaw_rate_des = np.zeros(B) if yaw_rate_des is None else np.asarray(yaw_rate_des, float)
+    bad_dt = (dt <= 0) | (dt > 0.1)                                           # :279
+    run = ~bad_dt
+    scale = 0.5 ** st.halvings.astype(float)
+    kp_pos, kd_pos = cfg.kp_pos * scale[:, None], cfg.kd_pos * scale[:, None]
+    kp_att, kd_att = cfg.kp_att * scale[:, None], cfg.kd_att * scale[:, None]
+    pos_error, vel_error = dpos - pos, dvel - vel                             # :283-284
+    acc_pid = kp_pos * pos_error + kd_pos * vel_error + cfg.ki_pos * st.integral   # :293-297
+    tvw = (dacc + acc_pid) - _a(0.0, 0.0, -veh.gravity)                       # :298, :301
+    tm = _norm(tvw)                                                           # :302
+    st.unsaturated_thrust[run] = tm[run]                                      # :305
+    min_thrust = cfg.min_thrust * veh.mass * veh.gravity                      # :127
+    hi, lo = tm > cfg.max_thrust, tm < min_thrust
+    tm = np.where(hi, cfg.max_thrust, np.where(lo, min_thrust, tm))           # :312-320
+    thrust_sat = hi | lo
+    st.thrust_saturated[run] = thrust_sat[run]                                # :322
+    update_integral_error(st, cfg, vel_error, dt, thrust_sat, run)            # :325
+    with np.errstate(divide="ignore", invalid="ignore"):
+        b3 = np.where((tm > 1e-6)[:, None], tvw / tm[:, None], _a(0.0, 0.0, 1.0))   # :328-331
+        tilt = np.arccos(np.clip(b3[:, 2], -1, 1))                            # :334
+        over = tilt > cfg.max_tilt_angle
+        ct = np.cos(cfg.max_tilt_angle)
+        sf = ct / b3[:, 2]
+        b3t = np.stack([b3[:, 0] * sf, b3[:, 1] * sf, np.full(B, ct)], axis=1)
+        b3t = b3t / _norm(b3t)[:, None]                                       # :335-339
+        b3 = np.where(over[:, None], b3t, b3)
+        b1, b2, b3n, singular = desired_frame(cfg, b3, att, yaw_des)          # :359-385
+    R = euler_to_rotation_matrix(att)
+    Rd = np.stack([b1, b2, b3n], axis=2)
+    M = np.einsum("bki,bkj->bij", Rd, R) - np.einsum("bki,bkj->bij", R, Rd)   # :388
+    eR = 0.5 * np.stack([M[:, 2, 1], M[:, 0, 2], M[:, 1, 0]], axis=1)
+    eOmega = omega - np.stack([np.zeros(B), np.zeros(B), yaw_rate_des], axis=1)   # :391-392
+    coriolis = np.cross(omega, cfg.inertia * omega)                           # :396 (np.diag(inertia) @ omega)
+    torque = -kp_att * eR - kd_att * eOmega + coriolis                        # :397
+    st.unsaturated_torque[run] = torque[run]                                  # :400
+    sat = np.abs(torque) > cfg.max_torque_xyz                                 # :403-408
+    torque = np.where(sat, np.sign(torque) * cfg.max_torque_xyz, torque)
+    st.torque_saturated[run] = sat[run]                                       # :410
+    thrust = np.where(bad_dt, veh.mass * veh.gravity, tm)                     # :280
+    torque = np.where(bad_dt[:, None], 0.0, torque)
+    return thrust, torque, dict(bad_dt=bad_dt, thrust_saturated=thrust_sat & run, torque_saturated=sat & run[:, None], singular=singular & run,
+                                tilt_limited=over & run)
 
 
 def compute_body_rate_command(st, cfg, t, pos, vel, att, omega, dpos, dvel, dacc, yaw_des=None, yaw_rate_des=None):

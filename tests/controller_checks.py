@@ -110,6 +110,179 @@ def check_control_sequences(h, data, meta):
     return mism, calls
 
 
+def check_fast_sequences(h, data, meta):
+    """The reference's compute_control_fast / compute_control_from_fast_state sequences (alone, and interleaved with compute_control on one
+    controller record) through se3mpc_control_fast_* / se3mpc_control_*, call by call, with the controller members after each call and the
+    saturation counts the reference keeps (summed from the flags, as the mirror class does)."""
+    dt_ = h.dt
+    f64 = dt_ == np.float64
+    vc = meta["vehicle_constants"]
+    veh = co.VehicleConstants(mass=vc["mass"], gravity=vc["gravity"])
+    mism = calls = 0
+    for seq in meta["fast_sequences"]:
+        k = seq["key"]
+        cfg = oracle_config(seq)
+        cp = ControllerParams.from_config(cfg)
+        st = h.ops.controller_state(cp, 1)
+        n_thrust = n_torque = 0
+        for i in range(seq["calls"]):
+            a = lambda nm: h.to_dev(np.ascontiguousarray(data[k + nm][i][None].astype(dt_)))
+            s1 = lambda nm: h.to_dev(np.array([data[k + nm][i]], dtype=dt_))
+            before = h.to_host(st).copy()
+            fast = int(data[k + "path"][i]) == 1
+            if fast:
+                out = h.ops.control_fast(cp, st, float(data[k + "dt"][i]), a("pos"), a("vel"), a("att"), a("omega"), a("dpos"), a("dvel"), a("dacc"),
+                                         s1("yaw"), s1("yaw_rate"), vehicle_mass=vc["mass"], vehicle_gravity=vc["gravity"])
+                fl = int(h.to_host(out["flags"])[0])
+                n_thrust += int(bool(fl & 4)); n_torque += bin((fl >> 5) & 7).count("1")
+            else:
+                out = h.ops.control(cp, st, h.to_dev(np.array([data[k + "t"][i]], dtype=np.float64)), a("pos"), a("vel"), a("att"), a("omega"), a("dpos"),
+                                    a("dvel"), a("dacc"), s1("yaw"), s1("yaw_rate"))
+                fl = int(h.to_host(out["flags"])[0])
+            after = h.to_host(st)
+            calls += 1
+            if f64:
+                assert abs(float(h.to_host(out["thrust"])[0]) - data[k + "thrust"][i]) <= 1e-9, (k, i)
+                assert np.max(np.abs(h.to_host(out["torque"])[0] - data[k + "torque"][i])) <= 1e-9, (k, i)
+                assert np.max(np.abs(after[0, 0:3] - data[k + "integral"][i])) <= 1e-11, (k, i)
+                sf = int(after[0, 11])
+                assert bool(sf & 1) == bool(data[k + "failsafe_active"][i]) and bool(sf & 2) == bool(data[k + "thrust_saturated"][i]), (k, i)
+                assert [bool(sf & 4), bool(sf & 8), bool(sf & 16)] == [bool(x) for x in data[k + "torque_saturated"][i]], (k, i)
+                assert int(after[0, 9]) == int(data[k + "failsafe_count"][i]) and int(after[0, 10]) == int(data[k + "halvings"][i]), (k, i)
+                assert abs(after[0, 4] - data[k + "last_valid_thrust"][i]) <= 1e-9 and abs(after[0, 5] - data[k + "unsaturated_thrust"][i]) <= 1e-9, (k, i)
+                assert (n_thrust, n_torque) == (int(data[k + "thrust_saturation_count"][i]), int(data[k + "torque_saturation_count"][i])), (k, i)
+                if fast:
+                    assert after[0, 3] == before[0, 3] or (after[0, 3] != after[0, 3] and before[0, 3] != before[0, 3]), (k, i)   # last_time untouched
+                    if fl & 2:                                                        # invalid dt: nothing changes (controller.py:279-280)
+                        assert np.array_equal(after, before, equal_nan=True), (k, i)
+            elif fast:
+                r = lambda nm: data[k + nm][i][None].astype(dt_).astype(float)
+                so = state_to_oracle(before, cfg)
+                th, tq, fo = co.compute_control_fast(so, cfg, veh, float(data[k + "dt"][i]), r("pos"), r("vel"), r("att"), r("omega"), r("dpos"), r("dvel"),
+                                                     r("dacc"), np.array([float(dt_(data[k + "yaw"][i]))]), np.array([float(dt_(data[k + "yaw_rate"][i]))]))
+                same = (bool(fl & 2) == bool(fo["bad_dt"][0]) and bool(fl & 4) == bool(fo["thrust_saturated"][0]) and bool(fl & 8) == bool(fo["singular"][0])
+                        and bool(fl & 16) == bool(fo["tilt_limited"][0]) and [bool(fl & 32), bool(fl & 64), bool(fl & 128)] == [bool(x) for x in fo["torque_saturated"][0]])
+                if not same:
+                    mism += 1
+                    continue
+                assert abs(float(h.to_host(out["thrust"])[0]) - th[0]) <= 2e-5 * max(1.0, abs(th[0])), (k, i)
+                assert np.max(np.abs(h.to_host(out["torque"])[0] - tq[0])) <= 2e-4, (k, i)
+                assert np.max(np.abs(after[0, 0:3] - so.integral[0])) <= 1e-5, (k, i)
+    assert mism <= 0.02 * calls, (mism, calls)
+    return mism, calls
+
+
+def check_fast_batch_vs_oracle(h, B=300, calls=6, seed=0):
+    """A random batch through se3mpc_control_fast_* against the oracle, state carried over `calls` calls (f64: every output and the record;
+    f32: from the same record each call)."""
+    rng = np.random.default_rng(seed)
+    cfg = oracle_config()
+    cp = ControllerParams.from_config(cfg)
+    veh = co.VehicleConstants()
+    st = h.ops.controller_state(cp, B)
+    so = co.ControllerState(B, cfg)
+    f64 = h.dt == np.float64
+    worst = 0.0
+    for c in range(calls):
+        r3 = lambda s: rng.normal(0, s, (B, 3)).astype(h.dt)
+        pos, vel, att, om = r3(3.0), r3(1.0), r3(0.4), r3(1.0)
+        dpos, dvel, dacc = pos + r3(1.0), vel + r3(1.0), r3(2.0)
+        yaw, yr = rng.uniform(-3, 3, B).astype(h.dt), rng.normal(0, 0.5, B).astype(h.dt)
+        dt = [0.0025, 0.001, 0.2, 0.01, 0.0025, 0.05][c % 6]
+        if not f64:
+            so = state_to_oracle(h.to_host(st).copy(), cfg)
+        out = h.ops.control_fast(cp, st, dt, *(h.to_dev(x) for x in (pos, vel, att, om, dpos, dvel, dacc, yaw, yr)), vehicle_mass=veh.mass,
+                                 vehicle_gravity=veh.gravity)
+        f = lambda x: x.astype(float)
+        th, tq, fo = co.compute_control_fast(so, cfg, veh, dt, f(pos), f(vel), f(att), f(om), f(dpos), f(dvel), f(dacc), f(yaw), f(yr))
+        fl = h.to_host(out["flags"])
+        same = (((fl & 2) != 0) == fo["bad_dt"]) & (((fl & 4) != 0) == fo["thrust_saturated"]) & (((fl & 8) != 0) == fo["singular"]) & \
+               (((fl & 16) != 0) == fo["tilt_limited"]) & np.all(np.stack([(fl & 32) != 0, (fl & 64) != 0, (fl & 128) != 0], 1) == fo["torque_saturated"], axis=1)
+        if f64:
+            assert same.all(), (c, int((~same).sum()))
+            e = max(float(np.max(np.abs(h.to_host(out["thrust"]) - th))), float(np.max(np.abs(h.to_host(out["torque"]) - tq))),
+                    float(np.max(np.abs(h.to_host(st)[:, 0:3] - so.integral))))
+            assert e <= 1e-9, (c, e)
+            worst = max(worst, e)
+        else:
+            assert same.mean() >= 0.97, (c, float(same.mean()))
+            e = float(np.max(np.abs(h.to_host(out["thrust"])[same] - th[same]) / np.maximum(1.0, np.abs(th[same]))))
+            assert e <= 2e-5 and float(np.max(np.abs(h.to_host(out["torque"])[same] - tq[same]))) <= 3e-4, (c, e)
+            worst = max(worst, e)
+    return worst
+
+
+def check_building_blocks(h, B=200, seed=0):
+    """se3mpc_controller_integral_update / attitude_torque / desired_frame against the oracle on random batches, and the known answers the
+    reference's own controller tests hold (tests/test_controller_torque_calculation.py:20-92: with zero attitude gains the torque is the
+    Coriolis term w x (I w), diagonal and full inertia, rtol 1e-10; tests/control/test_geometric_controller_yaw_singularity.py:215-233:
+    cos_angle is |yaw_vector . b3| exactly, singular at >= the threshold)."""
+    rng = np.random.default_rng(seed)
+    f64 = h.dt == np.float64
+    tol = 1e-10 if f64 else 2e-5
+    dev = lambda a: h.to_dev(np.ascontiguousarray(np.asarray(a, dtype=h.dt)))
+    # ---- Coriolis known answers
+    cfg = oracle_config()
+    cfg.kp_att = np.zeros(3); cfg.kd_att = np.zeros(3); cfg.inertia = np.array([0.025, 0.03, 0.045]); cfg.max_torque_xyz = np.array([100.0, 100.0, 100.0])
+    cp = ControllerParams.from_config(cfg)
+    st = h.ops.controller_state(cp, 1)
+    w = np.array([[0.1, 0.2, 0.3]])
+    up = np.array([[0.0, 0.0, 1.0]])
+    out = h.ops.controller_attitude_torque(cp, st, dev(np.zeros((1, 3))), dev(w), dev(up))
+    assert np.allclose(h.to_host(out["torque"])[0], np.cross(w[0], cfg.inertia * w[0]), rtol=1e-10 if f64 else 1e-5, atol=0 if f64 else 1e-9)
+    full = np.array([[0.02, 0.001, 0.002], [0.001, 0.02, 0.003], [0.002, 0.003, 0.04]])
+    out = h.ops.controller_attitude_torque(cp, st, dev(np.zeros((1, 3))), dev(w), dev(up), inertia=full)
+    assert np.allclose(h.to_host(out["torque"])[0], np.cross(w[0], full @ w[0]), rtol=1e-10 if f64 else 1e-5, atol=0 if f64 else 1e-9)
+    out = h.ops.controller_attitude_torque(cp, st, dev(np.zeros((1, 3))), dev(np.zeros((1, 3))), dev(up))
+    assert not h.to_host(out["torque"]).any()
+    # ---- singularity detection known answers
+    cp0 = ControllerParams.from_config(oracle_config())
+    for z, sing in ((0.0, False), (0.95, True), (-0.95, True), (0.5, True), (0.1, True), (0.09, False)):
+        r = h.ops.controller_desired_frame(cp0, dev([[0.0, 0.0, z]]), dev(up))
+        assert float(h.to_host(r["cos_angle"])[0]) == float(h.dt(abs(z))) and bool(h.to_host(r["singular"])[0]) == sing, z
+    # ---- frames against the oracle: the attitude law's own construction (method -1) and each fallback forced
+    yaw = rng.uniform(-3, 3, B); cur = rng.uniform(-3, 3, B)
+    b3 = rng.normal(0, 1, (B, 3)); b3[: B // 4, :2] *= 0.02; b3 /= np.linalg.norm(b3, axis=1)[:, None]
+    yv = np.stack([np.cos(yaw), np.sin(yaw), np.zeros(B)], 1)
+    b3r, yvr, curr = (np.asarray(a, h.dt).astype(float) for a in (b3, yv, cur))
+    att = np.stack([np.zeros(B), np.zeros(B), curr], 1)
+    for name, code in (("skip_yaw", 0), ("default_heading", 1), ("maintain_current", 2), ("something_else", 3)):
+        c2 = oracle_config(); c2.yaw_singularity_fallback_method = name; c2.default_heading_yaw = 0.7
+        cpx = ControllerParams.from_config(c2)
+        # forced fallback == the oracle's frame with the threshold at 0 (everything singular)
+        c3 = oracle_config(); c3.yaw_singularity_fallback_method = name; c3.default_heading_yaw = 0.7; c3.yaw_singularity_threshold = 0.0
+        for method, ocfg in ((-1, c2), (code, c3)):
+            r = h.ops.controller_desired_frame(cpx, dev(yv), dev(b3), dev(cur), method)
+            # the oracle takes yaw angles: rebuild them from the rounded vector so both see the same input
+            b1, b2, b3n, sg = co.desired_frame(ocfg, b3r, att, np.arctan2(yvr[:, 1], yvr[:, 0]))
+            fr = h.to_host(r["frame"]).astype(float)
+            same = (h.to_host(r["singular"]).astype(bool) == sg) if method < 0 else np.ones(B, bool)
+            assert same.mean() >= (1.0 if f64 else 0.98), (name, method)
+            e = max(float(np.max(np.abs(fr[same, 0:3] - b1[same]))), float(np.max(np.abs(fr[same, 3:6] - b2[same]))))
+            assert e <= (1e-9 if f64 else 3e-4), (name, method, e)
+    # ---- _update_integral_error against the oracle, both methods, explicit saturation arguments
+    for method in ("clamping", "back_calculation", "neither"):
+        c2 = oracle_config(); c2.anti_windup_method = method
+        cpx = ControllerParams.from_config(c2)
+        st = h.ops.controller_state(cpx, B)
+        so = co.ControllerState(B, c2)
+        for _ in range(4):
+            ve = rng.normal(0, 30.0, (B, 3)).astype(h.dt)
+            sat = rng.integers(0, 16, B).astype(np.int32)
+            rows = h.to_host(st).copy()
+            rows[:, 5] = rng.uniform(15, 30, B); rows[:, 6:9] = rng.normal(0, 1, (B, 3))        # unsaturated thrust / torques the back-calculation reads
+            rows = rows.astype(h.dt).astype(np.float64) if not f64 else rows
+            st = h.to_dev(np.ascontiguousarray(rows))
+            so = state_to_oracle(rows, c2)
+            so.torque_saturated = np.stack([(sat & 2) != 0, (sat & 4) != 0, (sat & 8) != 0], 1)
+            co.update_integral_error(so, c2, ve.astype(float), np.full(B, 0.01), (sat & 1) != 0, np.ones(B, bool))
+            h.ops.controller_integral_update(cpx, st, h.to_dev(ve), 0.01, h.to_dev(sat))
+            after = h.to_host(st)
+            assert np.max(np.abs(after[:, 0:3] - so.integral)) <= (1e-12 if f64 else 2e-5), method
+            assert np.array_equal(after[:, 3:], rows[:, 3:], equal_nan=True)                    # nothing but the integral moves
+    return True
+
+
 def check_closed_loops_golden(h, data, meta):
     """The reference's closed loops (planner plan -> sampler -> controller -> simulator) in ONE launch each, per-step logs against
     the reference's own."""

@@ -13,6 +13,10 @@ RUNNING THE REFERENCE'S OWN CLASSES in the build container:
   tests (tests/test_planner_controller_contract.py:115-162, :255-316: nominal, constant wind, gust at step 50,
   actuator saturation, emergency hover), with the wall clock pinned so the run is reproducible.
 
+* ``compute_control_fast`` / ``compute_control_from_fast_state`` (:253-411, :728-768), the unit-free path of the reference's
+  400 Hz hardware loop (hardware/pixhawk_interface.py:401): own sequences, and sequences that interleave it with
+  ``compute_control`` on one controller (shared integral, gains, saturation flags).
+
 Same stand-ins as make_golden.py (identity units for the missing ``pint``).  Writes controller_cases.npz / .json.
 """
 import json
@@ -229,10 +233,81 @@ def main():
         meta["loops"] = loops
         meta["T0"] = T0
 
+        # ------------------------------------------------------------------ E. the unit-free "fast" path of the 400 Hz hardware loop
+        # compute_control_fast / compute_control_from_fast_state (controller.py:253-411, :728-768; caller hardware/pixhawk_interface.py:401):
+        # dt is an argument, an invalid dt returns the vehicle's hover thrust without touching the failsafe, mass and gravity come from
+        # common/vehicle_params.py (not the controller config), saturations are counted.  Own random stream: sections A-D keep their bytes.
+        from dart_planner.common.types import FastDroneState
+        rng_f = np.random.default_rng(20261005)
+        meta["vehicle_constants"] = dict(mass=float(c0._fast_mass), gravity=float(c0._fast_gravity_magnitude),
+                                         gravity_vector=np.asarray(c0._fast_gravity_vector, float).tolist(), min_thrust=float(c0._fast_min_thrust))
+        fast = []
+        fkinds = ["small", "small", "large", "descend", "attitude", "bad_dt", "bad_dt", "back_calculation", "maintain_current", "default_heading",
+                  "fast_state", "interleaved", "interleaved", "yawed"]
+        for si, kind in enumerate(fkinds):
+            conf = GeometricControllerConfig()
+            if kind == "back_calculation":
+                conf.anti_windup_method = "back_calculation"
+            if kind in ("default_heading", "maintain_current"):
+                conf.yaw_singularity_fallback_method = kind
+                conf.default_heading_yaw = -1.1
+            ctrl = GeometricController(config=conf, tuning_profile="sitl_optimized")
+            T = 40
+            spread = dict(small=0.05, large=6.0, descend=2.0, attitude=0.3, bad_dt=0.5, back_calculation=4.0, maintain_current=0.5, default_heading=0.5,
+                          fast_state=0.4, interleaved=1.5, yawed=0.5)[kind]
+            t = 300.0 + si
+            rec = {k: [] for k in ("t", "dt", "path", "pos", "vel", "att", "omega", "dpos", "dvel", "dacc", "yaw", "yaw_rate", "thrust", "torque",
+                                   "integral", "failsafe_active", "failsafe_count", "halvings", "last_valid_thrust", "torque_saturated",
+                                   "thrust_saturated", "unsaturated_thrust", "thrust_saturation_count", "torque_saturation_count")}
+            pos = rng_f.uniform(-5, 5, 3); vel = rng_f.uniform(-1, 1, 3)
+            for k in range(T):
+                dt = [0.0025, 0.001][si % 2]
+                if kind == "bad_dt":
+                    dt = [0.0025, 0.0, -0.01, 0.2, 0.1, 0.1000001, 0.05][rng_f.integers(0, 7)]
+                path = 1                                        # 1 fast, 0 compute_control (same controller: shared integral, gains, flags)
+                if kind == "interleaved":
+                    path = int(rng_f.integers(0, 2)) if k not in (20, 21) else 0
+                t += 0.0025 if not (kind == "interleaved" and k == 21) else 0.0     # two compute_control calls on one stamp: its failsafe halves the gains the fast path reads
+                att = rng_f.normal(0, 0.05 if kind != "attitude" else 0.6, 3)
+                if kind == "yawed":
+                    att[2] = rng_f.uniform(-3, 3)
+                omega = rng_f.normal(0, 0.2 if kind != "attitude" else 2.0, 3)
+                pos = pos + rng_f.normal(0, 0.02, 3); vel = vel + rng_f.normal(0, 0.05, 3)
+                dpos = pos + rng_f.normal(0, spread, 3); dvel = vel + rng_f.normal(0, spread, 3); dacc = rng_f.normal(0, 0.5 * spread, 3)
+                if kind == "descend":
+                    dacc[2] -= 9.0
+                yaw = float(rng_f.uniform(-3.1, 3.1)) if kind in ("attitude", "default_heading", "maintain_current", "yawed") else 0.0
+                yaw_rate = float(rng_f.normal(0, 0.5)) if kind in ("attitude", "yawed") else 0.0
+                if path == 0:
+                    cmd = ctrl.compute_control(mkstate(t, pos, vel, att, omega), dpos.copy(), dvel.copy(), dacc.copy(), yaw, yaw_rate)
+                    thrust, torque = float(cmd.thrust), np.array(cmd.torque, float)
+                elif kind == "fast_state":
+                    fs = FastDroneState(timestamp=float(t), position=pos.copy(), velocity=vel.copy(), attitude=att.copy(), angular_velocity=omega.copy())
+                    thrust, torque = ctrl.compute_control_from_fast_state(fs, dpos.copy(), dvel.copy(), dacc.copy(), yaw, yaw_rate, dt)
+                else:
+                    thrust, torque = ctrl.compute_control_fast(pos.copy(), vel.copy(), att.copy(), omega.copy(), dpos.copy(), dvel.copy(), dacc.copy(),
+                                                               yaw, yaw_rate, dt)
+                snap = snapshot(ctrl)
+                snap.update(unsaturated_thrust=float(ctrl.unsaturated_thrust), thrust_saturation_count=int(ctrl._thrust_saturation_count),
+                            torque_saturation_count=int(ctrl._torque_saturation_count))
+                for nm, v in (("t", t), ("dt", dt), ("path", path), ("pos", pos), ("vel", vel), ("att", att), ("omega", omega), ("dpos", dpos),
+                              ("dvel", dvel), ("dacc", dacc), ("yaw", yaw), ("yaw_rate", yaw_rate), ("thrust", float(thrust)),
+                              ("torque", np.array(torque, float))):
+                    rec[nm].append(np.array(v, float))
+                for nm in ("integral", "failsafe_active", "failsafe_count", "halvings", "last_valid_thrust", "torque_saturated", "thrust_saturated",
+                           "unsaturated_thrust", "thrust_saturation_count", "torque_saturation_count"):
+                    rec[nm].append(snap[nm])
+            key = f"f{si:02d}_"
+            for nm, v in rec.items():
+                out[key + nm] = np.array(v)
+            fast.append(dict(key=key, kind=kind, calls=T, anti_windup=conf.anti_windup_method, fallback=conf.yaw_singularity_fallback_method,
+                             default_heading_yaw=float(conf.default_heading_yaw)))
+        meta["fast_sequences"] = fast
+
         np.savez_compressed(os.path.join(OUT_DIR, "controller_cases.npz"), **out)
         with open(os.path.join(OUT_DIR, "controller_cases.json"), "w") as f:
             json.dump(meta, f, indent=1)
-        print("wrote controller_cases.npz / .json:", len(seqs), "sequences,", len(loops), "closed loops")
+        print("wrote controller_cases.npz / .json:", len(seqs), "sequences,", len(loops), "closed loops,", len(fast), "fast-path sequences")
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

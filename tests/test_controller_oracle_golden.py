@@ -65,6 +65,47 @@ def test_controller_call_sequences(golden_controller):
     assert all(seen[nm] >= 10 for nm in ("failsafe", "thrust_saturated", "singular", "tilt_limited", "torque_saturated")), seen
 
 
+def test_controller_fast_path_sequences(golden_controller):
+    """compute_control_fast / compute_control_from_fast_state (the 400 Hz hardware loop's path), alone and interleaved with
+    compute_control on one controller, call by call against the reference's own returns and members."""
+    data, meta = golden_controller
+    vc = meta["vehicle_constants"]
+    veh = co.VehicleConstants()
+    assert (veh.mass, veh.gravity) == (vc["mass"], vc["gravity"]) and vc["gravity_vector"] == [0.0, 0.0, -vc["gravity"]]
+    assert vc["min_thrust"] == meta["config"]["min_thrust"] * vc["mass"] * vc["gravity"]
+    seen = dict(bad_dt=0, thrust_saturated=0, singular=0, tilt_limited=0, unsaturated_axis=0, fast=0, normal=0, halved_fast=0)
+    for seq in meta["fast_sequences"]:
+        k = seq["key"]
+        cfg = config_from_meta(meta, seq)
+        st = co.ControllerState(1, cfg)
+        n_thrust = n_torque = 0
+        for i in range(seq["calls"]):
+            a = lambda nm: data[k + nm][i][None].astype(float)
+            if int(data[k + "path"][i]) == 0:
+                thrust, torque, _ = co.compute_control(st, cfg, a("t"), a("pos"), a("vel"), a("att"), a("omega"), a("dpos"), a("dvel"), a("dacc"),
+                                                       a("yaw"), a("yaw_rate"))
+                seen["normal"] += 1
+            else:
+                thrust, torque, fl = co.compute_control_fast(st, cfg, veh, a("dt"), a("pos"), a("vel"), a("att"), a("omega"), a("dpos"), a("dvel"),
+                                                             a("dacc"), a("yaw"), a("yaw_rate"))
+                n_thrust += int(fl["thrust_saturated"][0]); n_torque += int(fl["torque_saturated"][0].sum())     # :315-320, :404
+                for nm in ("bad_dt", "thrust_saturated", "singular", "tilt_limited"):
+                    seen[nm] += int(fl[nm][0])
+                seen["unsaturated_axis"] += int((~fl["torque_saturated"][0]).sum() if not fl["bad_dt"][0] else 0)
+                seen["fast"] += 1
+                seen["halved_fast"] += int(st.halvings[0] > 0)
+            assert abs(thrust[0] - data[k + "thrust"][i]) <= 1e-10, (k, i, thrust, data[k + "thrust"][i])
+            assert np.max(np.abs(torque[0] - data[k + "torque"][i])) <= 1e-10, (k, i)
+            assert np.max(np.abs(st.integral[0] - data[k + "integral"][i])) <= 1e-12, (k, i)
+            assert bool(st.failsafe_active[0]) == bool(data[k + "failsafe_active"][i]) and int(st.failsafe_count[0]) == int(data[k + "failsafe_count"][i]), (k, i)
+            assert int(st.halvings[0]) == int(data[k + "halvings"][i]), (k, i)
+            assert abs(st.last_valid_thrust[0] - data[k + "last_valid_thrust"][i]) <= 1e-10, (k, i)
+            assert np.array_equal(st.torque_saturated[0], data[k + "torque_saturated"][i]) and bool(st.thrust_saturated[0]) == bool(data[k + "thrust_saturated"][i]), (k, i)
+            assert abs(st.unsaturated_thrust[0] - data[k + "unsaturated_thrust"][i]) <= 1e-10, (k, i)
+            assert (n_thrust, n_torque) == (int(data[k + "thrust_saturation_count"][i]), int(data[k + "torque_saturation_count"][i])), (k, i)
+    assert all(seen[nm] >= 10 for nm in seen), seen
+
+
 def test_controller_batched_equals_one_by_one(golden_controller):
     """The oracle is batched over drones: stacking all sequences as a batch gives the same numbers as one at a time."""
     data, meta = golden_controller

@@ -177,6 +177,18 @@ def test_control_reproduces_reference_sequences(emu_ops, golden_controller, dt):
     cc.check_control_sequences(harness(emu_ops, dt), data, meta)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_control_fast_reproduces_reference_sequences(emu_ops, golden_controller, dt):
+    data, meta = golden_controller
+    cc.check_fast_sequences(harness(emu_ops, dt), data, meta)
+    cc.check_fast_batch_vs_oracle(harness(emu_ops, dt), B=70, calls=6, seed=5)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_controller_building_blocks(emu_ops, dt):
+    cc.check_building_blocks(harness(emu_ops, dt), B=60, seed=7)
+
+
 def test_closed_loop_reproduces_reference_loops(emu_ops, golden_controller):
     data, meta = golden_controller
     assert cc.check_closed_loops_golden(harness(emu_ops, np.float64), data, meta) <= 1e-8
@@ -190,7 +202,7 @@ def test_closed_loop_random_batch_vs_oracle(emu_ops, dt):
 
 
 def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
-    """se3mpc_rollout_iterate / projected_step / control / control_plan / simulator_step / closed_loop / controller_reset:
+    """se3mpc_rollout_iterate / projected_step / control / control_fast / control_plan / simulator_step / closed_loop / controller_reset:
     B == 0 is a no-op, NULL and shape errors come back as status codes, bad parameter structs are refused."""
     lib, be = emu_ops.lib, emu_ops.be
     prm = capi.Params.reference_defaults(horizon=6)
@@ -222,6 +234,14 @@ def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
     bad = lib.controller_default_params(); bad.yaw_fallback_method = 7
     assert ctl(bad, 2, p(t), p(z3), p(state)) == -4
     assert lib._dll.se3mpc_controller_reset(None, 2, p(state), 0) == -1
+    fst = lambda cpx, m, g, B, dt, pos, stt: ls("control_fast", "f64", cpx, m, g, B, dt, pos, p(z3), p(z3), p(z3), p(z3), p(z3), 0, 0, 0, stt, p(th), p(tq), 0, 0)
+    assert fst(cp, 1.0, 9.80665, 0, 0.0025, 0, 0) == 0 and fst(cp, 1.0, 9.80665, 2, 0.0025, p(z3), p(state)) == 0
+    assert fst(cp, 1.0, 9.80665, 2, 0.5, p(z3), p(state)) == 0                 # an invalid dt is an answer of the path (hover thrust), not an error
+    assert th[0] == 9.80665 and not tq.any()
+    assert fst(cp, 1.0, 9.80665, 2, 0.0025, 0, p(state)) == -1 and fst(cp, 1.0, 9.80665, 2, 0.0025, p(z3), 0) == -1
+    assert fst(cp, 1.0, 9.80665, -1, 0.0025, p(z3), p(state)) == -3
+    assert fst(cp, 0.0, 9.80665, 2, 0.0025, p(z3), p(state)) == -4 and fst(cp, 1.0, float("nan"), 2, 0.0025, p(z3), p(state)) == -4
+    assert fst(cp, 1.0, 9.80665, 2, float("nan"), p(z3), p(state)) == -4 and fst(bad, 1.0, 9.80665, 2, 0.0025, p(z3), p(state)) == -4
     ts = np.array([0.0, 1.0]); P = np.zeros((2, 3))
     loop = lambda spx, B, nsteps, dt, N, tsp, Pp: ls("closed_loop", "f64", cp, spx, B, nsteps, dt, N, tsp, 0, Pp, 0, 0, 0, 0, 0, p(t), p(z3), p(z3), p(z3), p(z3),
                                                      p(state), 0, 0, -1, None, 1, 0, 0, 0, 0, 0)

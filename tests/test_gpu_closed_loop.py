@@ -49,6 +49,49 @@ def test_control_reproduces_reference_sequences(gpu_ops, golden_controller, dt):
     print(f"{np.dtype(dt).name}: {calls} controller calls, {mism} on another side of a branch")
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_control_fast_reproduces_reference_sequences(gpu_ops, golden_controller, dt):
+    """compute_control_fast / compute_control_from_fast_state (the reference's 400 Hz hardware loop path), alone and interleaved with
+    compute_control on one controller record, against the reference's own returns; then a 4096-drone batch against the oracle."""
+    data, meta = golden_controller
+    mism, calls = cc.check_fast_sequences(harness(gpu_ops, dt), data, meta)
+    worst = cc.check_fast_batch_vs_oracle(harness(gpu_ops, dt), B=4096, calls=6, seed=6)
+    print(f"{np.dtype(dt).name}: {calls} fast-path calls, {mism} on another side of a branch; 4096-drone batch worst {worst:.2e}")
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_controller_building_blocks(gpu_ops, dt):
+    """_update_integral_error, _geometric_attitude_control / _fast_geometric_attitude_control, _detect_yaw_singularity / _handle_yaw_singularity
+    as device entry points: the oracle on random batches and the known answers of the reference's own controller tests."""
+    cc.check_building_blocks(harness(gpu_ops, dt), B=2048, seed=8)
+
+
+def test_controller_mirror_fast_path(gpu_ops, golden_controller):
+    """The mirror class's compute_control_fast / compute_control_from_fast_state and the members the reference's own controller tests read
+    (integral_vel_error, last_thrust_saturated, unsaturated_thrust, the saturation counts of get_performance_metrics)."""
+    from dart_planner_amd.control.geometric_controller import GeometricController, GeometricControllerConfig
+    from dart_planner_amd.common.types import FastDroneState
+    data, meta = golden_controller
+    seq = next(s for s in meta["fast_sequences"] if s["kind"] == "fast_state")
+    k = seq["key"]
+    ctrl = GeometricController(config=GeometricControllerConfig(), tuning_profile="sitl_optimized")
+    ctrl._ops = gpu_ops
+    for i in range(seq["calls"]):
+        fs = FastDroneState(timestamp=float(data[k + "t"][i]), position=data[k + "pos"][i], velocity=data[k + "vel"][i], attitude=data[k + "att"][i],
+                            angular_velocity=data[k + "omega"][i])
+        thrust, torque = ctrl.compute_control_from_fast_state(fs, data[k + "dpos"][i], data[k + "dvel"][i], data[k + "dacc"][i], float(data[k + "yaw"][i]),
+                                                              float(data[k + "yaw_rate"][i]), float(data[k + "dt"][i]))
+        assert abs(thrust - data[k + "thrust"][i]) <= 1e-9 and np.max(np.abs(torque - data[k + "torque"][i])) <= 1e-9, i
+        assert np.max(np.abs(ctrl.integral_vel_error - data[k + "integral"][i])) <= 1e-11
+        assert abs(ctrl.unsaturated_thrust - data[k + "unsaturated_thrust"][i]) <= 1e-9 and ctrl.last_thrust_saturated == bool(data[k + "thrust_saturated"][i])
+    m = ctrl.get_performance_metrics()
+    assert m["thrust_saturation_count"] == int(data[k + "thrust_saturation_count"][-1]) and m["torque_saturation_count"] == int(data[k + "torque_saturation_count"][-1])
+    assert ctrl.last_time is None                      # the fast path never stamps the controller (controller.py:253-346)
+    # an invalid dt: the vehicle's hover thrust, zero torque (controller.py:279-280)
+    th, tq = ctrl.compute_control_fast(np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3), np.ones(3), np.zeros(3), np.zeros(3), dt=0.2)
+    assert th == 1.0 * 9.80665 and not tq.any()
+
+
 def test_closed_loop_reproduces_reference_loops(gpu_ops, golden_controller):
     data, meta = golden_controller
     worst = cc.check_closed_loops_golden(harness(gpu_ops, np.float64), data, meta)
