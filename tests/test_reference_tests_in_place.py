@@ -47,3 +47,13 @@ def test_reference_controller_test_files_run_unchanged():
     assert failed == {"test_acceleration_matches_desired", "test_torque_coriolis_term",
                       "TestGeometricControllerAntiWindup::test_integral_decay_near_limits"}, out[-3000:]
     assert len(passed) == 28, out[-3000:]
+
+
+def test_reference_planner_and_mapper_test_files_run_unchanged():
+    """tests/test_mapper_trace_ray.py, test_planner_performance.py (cfg-1: 101 solves), test_planner_controller_integration.py pass; and
+    tests/test_se3_mpc_with_mapper.py ends exactly where it ends on the reference: its five map-update + plan cycles
+    succeed, then its last line reads `planner.config.dt` from what the reference's DI container hands out as a dict."""
+    passed, failed, out = run_in_place(["test_mapper_trace_ray.py", "test_planner_performance.py", "test_planner_controller_integration.py",
+                                        "test_se3_mpc_with_mapper.py"])
+    assert failed == {"test_se3_mpc_with_live_mapping"} and len(passed) == 3, out[-3000:]
+    assert "'dict' object has no attribute 'dt'" in out and "test_se3_mpc_with_mapper.py:42" in out, out[-3000:]
