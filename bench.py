@@ -517,7 +517,7 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
         ts = []
         for i, g in enumerate(goals[:120]):
             t0 = time.perf_counter()
-            pl.plan_shooting(st, g, n_samples=B, iters=16, seed=i)
+            pl.plan_shooting(st, g, n_samples=B, iters=16, seed=0)      # one resident sample set (a new seed is a new set and a new graph capture)
             torch.cuda.synchronize()
             if i >= 20:
                 ts.append((time.perf_counter() - t0) * 1e3)

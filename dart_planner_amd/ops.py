@@ -26,6 +26,7 @@ assert INFO_DTYPE.itemsize == 24
 
 class TorchBackend:
     """PyTorch-ROCm tensors on a HIP device.  Refuses CPU tensors: there is no CPU path."""
+    graph_capable = True          # launches go to torch's current stream: a torch.cuda.graph capture records them
 
     def __init__(self, device=None):
         import torch

@@ -299,6 +299,7 @@ class SE3MPCPlanner(BasePlanner):
         accelerations / attitudes / body rates / thrust magnitudes extracted (``se3mpc_extract_*``).  Unlike the reference's solve, whose
         dynamics constraints never reach the optimiser, this plan satisfies the dynamics by construction."""
         import torch
+        import torch.distributed as dist
         from ..distributed import sharded_shooting_plan
         current_state, _, _ = self.sense(current_state, goal_position)
         ops = self._get_ops()
@@ -306,6 +307,9 @@ class SE3MPCPlanner(BasePlanner):
         N = self.se3_config.prediction_horizon
         p0 = np.asarray(to_float(current_state.position), float)
         v0 = np.asarray(to_float(current_state.velocity), float)
+        single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if single and getattr(ops.be, "graph_capable", False):
+            return self._plan_shooting_captured(ops, prm, p0, v0, int(n_samples), int(iters), float(step), float(sigma), int(seed), precision)
         best = sharded_shooting_plan(ops, prm, p0, v0, self.goal_position, n_samples, iters, step, sigma, seed, precision)
         dev = ops.be.device
         col = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, float).reshape(-1, 1))).to(dev)
@@ -314,9 +318,68 @@ class SE3MPCPlanner(BasePlanner):
         acc, att, rates, thr = ops.extract(prm, T)
         h = lambda a, shape: ops.be.to_host(a)[:, 0].reshape(shape).astype(float)
         self.last_result = dict(cost=float(ops.be.to_host(cost)[0]), sample=int(best["sample"]), owner=int(best["owner"]), n_samples=int(n_samples),
-                                iters=int(iters))
+                                iters=int(iters), T=best["T"])
         sol = {"positions": h(P, (N, 3)), "velocities": h(V, (N, 3)), "thrust_vectors": best["T"], "accelerations": h(acc, (N, 3)),
                "attitudes": h(att, (N, 3)), "body_rates": h(rates, (N, 3)), "thrusts": h(thr, (N,))}
+        return self._create_trajectory_from_solution(sol, time.time())
+
+    def _plan_shooting_captured(self, ops, prm, p0, v0, n_samples, iters, step, sigma, seed, precision) -> Trajectory:
+        """plan_shooting on one rank as ONE hipGraph replay: 72 B in through a pinned buffer, the sample set (fixed by its seed) resident,
+        iterate -> fold the argmin keys -> select the winner's thrust column BY ITS DEVICE-SIDE KEY -> roll it out with states -> extract,
+        one packed result back to a pinned buffer; the host synchronises once.  Same launches, same numbers as the eager path
+        (`distributed.sharded_shooting_plan` + rollout + extract), without its ~10 host round trips."""
+        import torch
+        from ..distributed import shooting_samples
+        N = prm.horizon
+        key = (N, n_samples, iters, step, sigma, seed, precision, bytes(prm))
+        g = self._shooting_graphs.get(key) if hasattr(self, "_shooting_graphs") else None
+        if g is None:
+            if not hasattr(self, "_shooting_graphs"):
+                self._shooting_graphs = {}
+            dev = ops.be.device
+            dt = torch.float32 if precision == "f32" else torch.float64
+            io = dict(h_in=torch.zeros(9, dtype=torch.float64).pin_memory(), d_in=torch.zeros(9, dtype=torch.float64, device=dev),
+                      h_out=torch.zeros(19 * N + 1, dtype=torch.float64).pin_memory(), h_key=torch.zeros(1, dtype=torch.int64).pin_memory(),
+                      samples=shooting_samples(prm, n_samples, sigma, seed, dev, dt), wk=torch.zeros(((n_samples + 63) // 64,), dtype=torch.int64, device=dev),
+                      best=torch.zeros(1, dtype=torch.int64, device=dev))
+
+            def body():
+                io["d_in"].copy_(io["h_in"], non_blocking=True)
+                c = io["d_in"].to(dt).view(3, 3, 1)
+                wide = c.expand(3, 3, n_samples).contiguous()
+                out = ops.rollout_iterate(prm, wide[0], wide[1], wide[2], io["samples"], iters, step, want_grad=False, wave_keys=io["wk"], index_base=0)
+                ops.reduce_keys(io["wk"].view(1, -1), io["best"])
+                tw = out["T"].index_select(1, io["best"] & 0xFFFFFFFF).to(torch.float64)   # the key's low word is the sample index (se3mpc_key_index)
+                one = io["d_in"].view(3, 3, 1)                                     # the winner is rolled out and extracted in f64, as the eager path does
+                cost, _, P, V = ops.rollout_cost_grad(prm, one[0], one[1], one[2], tw, want_grad=False, want_states=True)
+                acc, att, rates, thr = ops.extract(prm, tw)
+                packed = torch.cat([x.reshape(-1) for x in (P, V, tw, acc, att, rates, thr, cost)])
+                io["h_out"].copy_(packed, non_blocking=True)
+                io["h_key"].copy_(io["best"], non_blocking=True)
+
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()                                                             # warm-up outside the capture
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                body()
+            if len(self._shooting_graphs) >= 4:                                    # a new seed / sample count is a new resident sample set and a new capture
+                self._shooting_graphs.pop(next(iter(self._shooting_graphs)))
+            g = self._shooting_graphs[key] = (graph, io)
+        graph, io = g
+        io["h_in"][0:3] = torch.from_numpy(p0); io["h_in"][3:6] = torch.from_numpy(v0)
+        io["h_in"][6:9] = torch.from_numpy(np.asarray(self.goal_position, float))
+        graph.replay()
+        torch.cuda.current_stream(ops.be.device).synchronize()
+        r = io["h_out"].numpy()
+        kh = int(io["h_key"].numpy()[0]) & 0xFFFFFFFFFFFFFFFF
+        blk = lambda i: r[3 * N * i:3 * N * (i + 1)].reshape(N, 3).copy()
+        self.last_result = dict(cost=float(r[19 * N]), sample=int(ops.lib.key_index(kh)), owner=0, n_samples=n_samples, iters=iters, T=blk(2))
+        sol = {"positions": blk(0), "velocities": blk(1), "thrust_vectors": blk(2), "accelerations": blk(3), "attitudes": blk(4),
+               "body_rates": blk(5), "thrusts": r[18 * N:19 * N].copy()}
         return self._create_trajectory_from_solution(sol, time.time())
 
     def _create_warm_start(self, current_state: DroneState, N: int) -> np.ndarray:

@@ -419,6 +419,7 @@ def test_planner_shooting_plan(gpu_ops):
     st = DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.array([0.5, -0.2, 0.1]))
     goal = np.array([5.0, 3.0, 2.0])
     tr = pl.plan_shooting(st, goal, n_samples=S, iters=K, step=0.9, sigma=2.0, seed=3, precision="f32")
+    T_first = pl.last_result["T"].copy()
     assert tr.positions.shape == (N, 3) and tr.thrusts.shape == (N,) and np.all(tr.thrusts > 0)
     assert np.allclose(tr.positions[0], st.position) and np.allclose(tr.velocities[0], st.velocity)
     s_win = pl.last_result["sample"]
@@ -438,3 +439,14 @@ def test_planner_shooting_plan(gpu_ops):
     X = orc.pack(np.asarray(tr.positions)[None], np.asarray(tr.velocities)[None], Tw[None])
     R = orc.dynamics_residual(X, st.position[None], st.velocity[None], cfg)
     assert np.max(np.abs(R)) <= 1e-9
+    # plan_shooting replays one captured hipGraph; the eager chain of the same launches (what several ranks run) gives the same winner and numbers
+    from dart_planner_amd.distributed import sharded_shooting_plan
+    eager = sharded_shooting_plan(gpu_ops, pl._params(), st.position, st.velocity, goal, S, K, 0.9, 2.0, 3, "f32")
+    assert eager["sample"] == s_win and np.array_equal(eager["T"], T_first)
+    # replays are reproducible and follow their inputs
+    tr2 = pl.plan_shooting(st, goal, n_samples=S, iters=K, step=0.9, sigma=2.0, seed=3, precision="f32")
+    assert np.array_equal(tr2.positions, tr.positions) and np.array_equal(tr2.thrusts, tr.thrusts)
+    st3 = DroneState(timestamp=0.0, position=np.array([1.0, -2.0, 3.0]), velocity=np.array([0.0, 0.3, 0.0]))
+    tr3 = pl.plan_shooting(st3, np.array([-4.0, 0.0, 1.0]), n_samples=S, iters=K, step=0.9, sigma=2.0, seed=3, precision="f32")
+    e3 = sharded_shooting_plan(gpu_ops, pl._params(), st3.position, st3.velocity, np.array([-4.0, 0.0, 1.0]), S, K, 0.9, 2.0, 3, "f32")
+    assert pl.last_result["sample"] == e3["sample"] and np.array_equal(e3["T"], pl.last_result["T"]) and np.allclose(tr3.positions[0], st3.position)
