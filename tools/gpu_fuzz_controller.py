@@ -55,10 +55,28 @@ for pi, prof in enumerate(TUNING_PROFILES):
                     lc = out["log_cmd"].cpu().numpy()
                     act = log["active"]
                     assert np.nanmax(np.abs(lc[..., 0][act] - log["thrust"][act])) <= 1e-8
+            # the fast path (compute_control_fast) of the same configuration: 8 calls on one record per drone, f64, every output and the integral
+            veh = co.VehicleConstants()
+            stf = ops.controller_state(cp, B); sof = co.ControllerState(B, ocfg)
+            wfast = 0.0
+            for c in range(8):
+                r3 = lambda sc: rng.normal(0, sc, (B, 3))
+                fp, fv, fa, fo = r3(3.0), r3(1.0), r3(0.4), r3(1.0)
+                fdp, fdv, fda = fp + r3(1.0) * spread, fv + r3(1.0) * spread, r3(2.0)
+                fy, fyr = rng.uniform(-3, 3, B), rng.normal(0, 0.5, B)
+                fdt = [0.0025, 0.001, 0.2, 0.01, 0.0025, 0.05, -1.0, 0.1][c]
+                d64 = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, np.float64))).to(dev)
+                fo_ = ops.control_fast(cp, stf, fdt, d64(fp), d64(fv), d64(fa), d64(fo), d64(fdp), d64(fdv), d64(fda), d64(fy), d64(fyr),
+                                       vehicle_mass=veh.mass, vehicle_gravity=veh.gravity)
+                th, tq, _ = co.compute_control_fast(sof, ocfg, veh, fdt, fp, fv, fa, fo, fdp, fdv, fda, fy, fyr)
+                wfast = max(wfast, float(np.max(np.abs(fo_["thrust"].cpu().numpy() - th))), float(np.max(np.abs(fo_["torque"].cpu().numpy() - tq))),
+                            float(np.max(np.abs(stf.cpu().numpy()[:, 0:3] - sof.integral))))
+            assert wfast <= 1e-9, (prof, aw, fb, wfast)
+            tot["worst_fast_f64"] = max(tot.get("worst_fast_f64", 0.0), wfast)
             w64 = float(res["float64"].max()); ok32 = float(np.mean(res["float32"] <= 5e-2))
             assert w64 <= 1e-8, (prof, aw, fb, w64)
             tot["configs"] += 1; tot["drones"] += 2 * B; tot["worst_f64"] = max(tot["worst_f64"], w64); tot["f32_within_5e2"] = min(tot["f32_within_5e2"], ok32)
             print(json.dumps(dict(profile=prof, anti_windup=aw, fallback=fb, sim_dt=sim_dt, drones=B, steps=nsteps, worst_state_error_f64=w64,
-                                  f32_median_error=float(np.median(res["float32"])), f32_fraction_within_5e2=ok32)), flush=True)
+                                  f32_median_error=float(np.median(res["float32"])), f32_fraction_within_5e2=ok32, fast_path_worst_f64=wfast)), flush=True)
 tot["seconds"] = round(time.time() - t0, 1)
 print(json.dumps(tot))
