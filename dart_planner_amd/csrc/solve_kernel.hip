@@ -881,20 +881,19 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           if (info != 0) return;
           // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
 #pragma unroll
-          for (int j = 0; j < J; ++j) d[j] = (iwhere[j] <= 0) ? (-theta * (z[j] - x[j]) - g[j]) : 0.0;
+          for (int j = 0; j < J; ++j) {                        // every variable's value first, ONE select at the end (d stays 0 off the free set)
+            double t = -theta * (z[j] - x[j]) - g[j];
 #pragma unroll
-          for (int c = 0; c < C; ++c) {
-            const double a1 = mc[c], a2 = theta * mc[C + c];
-#pragma unroll
-            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * a1 + (double)WS(c, j) * a2;
+            for (int c = 0; c < C; ++c) t += (double)WY(c, j) * mc[c] + (double)WS(c, j) * (theta * mc[C + c]);
+            d[j] = (iwhere[j] <= 0) ? t : 0.0;
           }
-          // ---- subsm: wv = W'Z d ; wv = K^-1 wv
+          // ---- subsm: wv = W'Z d ; wv = K^-1 wv   (d is 0 off the free set: no condition inside the sums)
           double wr[2 * C];
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             double a1 = 0.0, a2 = 0.0;
 #pragma unroll
-            for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+            for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
             wr[c] = a1; wr[C + c] = a2;
           }
           wave_sum_n<2 * C>(wr);
@@ -1001,7 +1000,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
               if (c < col) {
                 const double b1 = wvr[c] / theta, b2 = wvr[kFastCol + c];
 #pragma unroll
-                for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) d[j] += (double)WY(c, j) * b1 + (double)WS(c, j) * b2;
+                for (int j = 0; j < J; ++j) {
+                  const double t = d[j] + ((double)WY(c, j) * b1 + (double)WS(c, j) * b2);
+                  d[j] = (iwhere[j] <= 0) ? t : d[j];
+                }
               }
             }
           } else {
