@@ -36,7 +36,7 @@ class ClosedLoopMonteCarlo:
         k = torch.arange(N, dtype=torch.float64, device=dev)
         logs = []
         for c in range(cycles):
-            sol = ops.solve(prm, pos, vel, goal)
+            sol = ops.solve(prm, pos, vel, goal, want_trajectory=True if log else "accelerations")
             stamps = (c * substeps * sim_dt) + k * prm.dt
             X = sol["x"]
             out = ops.closed_loop(self.controller, self.simulator, st, time, pos, vel, att, om, stamps, X, X[:, 3 * N:], sol["accelerations"],

@@ -1271,18 +1271,21 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     r.fun = f; r.nit = nit; r.nfev = nfev; r.status = status; r.task = task;
     infog[pb] = r;
   }
-  // a restart solve asks for x and info only (every trajectory output null): nothing to extract
-  if (accg == nullptr && attg == nullptr && ratesg == nullptr && thrustg == nullptr) return;
+  // a restart solve asks for x and info only (every trajectory output null): nothing to extract; a closed loop that reads the plan in
+  // place wants the accelerations but no attitudes / rates / thrust magnitudes: no frames to build
+  const bool want_frames = attg != nullptr || ratesg != nullptr || thrustg != nullptr;
+  if (!want_frames && accg == nullptr) return;
   // ---- _extract_solution_from_result (planner.py:582-654): T block -> LDS, lane k = step k
   __syncthreads();
 #pragma unroll
   for (int j = 2 * JB; j < J; ++j) {
     const int r = lane + kWave * (j % JB);
     if (r < n3) {
-      scratch[r] = x[j];
+      if (want_frames) scratch[r] = x[j];
       if (accg != nullptr) accg[(size_t)pb * 3 * N + r] = (IO)(x[j] / q.mass - (((code[j] >> 2) & 3) == 2 ? q.grav : 0.0));
     }
   }
+  if (!want_frames) return;
   __syncthreads();
   double* Rm = scratch + 3 * kWave;       // [9][64]: b1, b2, b3 of every step
   const bool have = lane < N;

@@ -626,9 +626,10 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ problem layout
-    def solve(self, params: Params, p0, v0, goal, x0=None, want_trajectory: bool = True):
+    def solve(self, params: Params, p0, v0, goal, x0=None, want_trajectory=True):
         """a7 (+a3, a4, a11, a12): batched L-BFGS-B solve, one wavefront per problem.
-        p0, v0, goal: (B, 3);  x0: (B, 9N) or None (reference cold start).
+        p0, v0, goal: (B, 3);  x0: (B, 9N) or None (reference cold start).  want_trajectory: True (all outputs), False (x and info only:
+        restart sweeps) or "accelerations" (x, info, accelerations: the kernel skips attitudes / rates / thrust magnitudes).
         -> dict(x (B,9N), info (device bytes), acc/att/rates (B,N,3), thrust (B,N))."""
         N = params.horizon
         for a, nm in ((p0, "p0"), (v0, "v0")) + (((goal, "goal"),) if params.has_goal else ()):
@@ -644,7 +645,9 @@ class Ops:
         X = self.be.empty((B, 9 * N), suf)
         info = self.be.empty((B * INFO_DTYPE.itemsize,), "u8")
         acc = att = rates = thrust = None
-        if want_trajectory:
+        if want_trajectory == "accelerations":                # what a closed loop reading the plan in place needs next to x (se3mpc_closed_loop_*)
+            acc = self.be.empty((B, N, 3), suf)
+        elif want_trajectory:
             acc, att, rates = (self.be.empty((B, N, 3), suf) for _ in range(3))
             thrust = self.be.empty((B, N), suf)
         self.lib.call("solve", suf, B, self.be.ptr(p0), self.be.ptr(v0), self.be.ptr(goal if params.has_goal else None),

@@ -432,6 +432,12 @@ def check_solver_extraction(h: Harness, N: int, B: int, seed: int = 3):
     assert np.max(np.abs(h.to_host(out["attitudes"]) - ex["attitudes"])) <= t["pos"]
     assert np.max(np.abs(h.to_host(out["body_rates"]) - ex["body_rates"])) <= t["rates"]
     vec_close(h.to_host(out["thrusts"]), ex["thrusts"], t["vec_rel"], "thrusts")
+    # the reduced output sets give the same bits for what they do return
+    oa = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal), x0=h.prob(X0), want_trajectory="accelerations")
+    ox = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal), x0=h.prob(X0), want_trajectory=False)
+    assert oa["attitudes"] is None and oa["body_rates"] is None and oa["thrusts"] is None and ox["accelerations"] is None
+    assert np.array_equal(h.to_host(oa["x"]), h.to_host(out["x"])) and np.array_equal(h.to_host(ox["x"]), h.to_host(out["x"]))
+    assert np.array_equal(h.to_host(oa["accelerations"]), h.to_host(out["accelerations"]))
     # cold start of the solver == a3 projected into the box (x0 = None path)
     out2 = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
     ref0 = orc.straight_line_init(p0.astype(h.dt).astype(float), v0.astype(h.dt).astype(float),
