@@ -8,6 +8,9 @@
 // ("planner.py" in the comments), unit-stripped.
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+#include <initializer_list>
+
 #include <algorithm>
 #include <cmath>
 
@@ -1411,6 +1414,87 @@ static inline int check_lane_args(const se3mpc_params* p, int B, int ld, long lo
   return SE3MPC_OK;
 }
 
+// ---- 16-byte accesses for the write-only / write-heavy streams at saturating batches: a lane owns FOUR consecutive trajectories, a wavefront
+// row access is one contiguous 1 KB (tools/probes/probe_rows.hip: a bare write stream of this layout runs at 5.7-5.9 TB/s with 16 B per
+// lane against 5.1-5.5 with a dword).  float only; taken when B and ld are multiples of 4, the operands 16-byte aligned and the batch fills
+// the chip with a quarter of the wavefronts (kWideMinBatch); the arithmetic per trajectory is the dword kernel's, statement for statement.
+constexpr int kWideMinBatch = 1 << 18;
+static int g_wide_select = 0;        // se3mpc_set_rollout_variant(+512 / +1024): never / whenever the shapes allow (default: from kWideMinBatch up)
+static bool wide_ok(int B, int ld, std::initializer_list<const void*> ptrs) {
+  if (g_wide_select == 1 || (g_wide_select == 0 && B < kWideMinBatch) || B < 4 || (B & 3) || (ld & 3)) return false;
+  for (const void* q : ptrs)
+    if (q != nullptr && (reinterpret_cast<uintptr_t>(q) & 15u)) return false;
+  return true;
+}
+
+__global__ void __launch_bounds__(192)
+init4_kernel(DevParams<float> q, int B4, int ld4, const vf4* __restrict__ p0, const vf4* __restrict__ v0, const vf4* __restrict__ goal,
+             int project, vf4* __restrict__ X) {
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int c = blk * kWave + (int)(threadIdx.x & (kWave - 1));       // column of four trajectories
+  if (c >= B4) return;
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
+  const int N = q.N, N3 = 3 * q.N;
+  const float denom = (float)(N - 1 > 1 ? N - 1 : 1);
+  const vf4 p = lane_ld4(p0 + (size_t)a * ld4 + c);
+  const vf4 v = lane_ld4(v0 + (size_t)a * ld4 + c);
+  const vf4 g = q.has_goal ? lane_ld4(goal + (size_t)a * ld4 + c) : p;
+#pragma unroll 4
+  for (int i = 0; i < N; ++i) {
+    vf4 pi, vi;
+    if (q.has_goal) {
+      const float alpha = (float)i / denom;                                 // planner.py:344
+      pi = (1.0f - alpha) * p + alpha * g;                                  // planner.py:345-347
+      const vf4 dv = ((alpha - (float)(i - 1) / denom) * (g - p)) / q.dt;   // as init_kernel's float32 form
+      vi = (i == 0) ? v : dv;
+    } else {
+      pi = p;
+      vi = (i == 0) ? v : splat4(0.0f);
+    }
+    float ti = (a == 2) ? q.hover : 0.0f;
+    if (project) {
+      for (int w = 0; w < 4; ++w) { pi[w] = fminf(fmaxf(pi[w], -q.pos_b), q.pos_b); vi[w] = fminf(fmaxf(vi[w], -q.v_max), q.v_max); }
+      ti = (a == 2) ? fminf(fmaxf(ti, q.tz_lo), q.tz_hi) : ti;
+    }
+    lane_st4(X + (size_t)(3 * i + a) * ld4 + c, pi);
+    lane_st4(X + (size_t)(N3 + 3 * i + a) * ld4 + c, vi);
+    lane_st4(X + (size_t)(2 * N3 + 3 * i + a) * ld4 + c, splat4(ti));
+  }
+}
+
+// a9 materialised, four trajectories per lane: the N*K residual rows are the traffic (planner.py:499-514; arithmetic as obstacle_residual_kernel)
+__global__ void __launch_bounds__(64)
+obstacle_residual4_kernel(DevParams<float> q, int B4, int ld4, const vf4* __restrict__ X, const float* __restrict__ spheres, int K,
+                          vf4* __restrict__ C, vf4* __restrict__ cmin, vf4* __restrict__ viol) {
+  __shared__ float sph[SE3MPC_MAX_SPHERES * 4];
+  for (int i = threadIdx.x; i < K; i += blockDim.x) {
+    sph[4 * i + 0] = spheres[4 * i + 0]; sph[4 * i + 1] = spheres[4 * i + 1]; sph[4 * i + 2] = spheres[4 * i + 2];
+    const float s = spheres[4 * i + 3] + q.margin;
+    sph[4 * i + 3] = s * s;
+  }
+  __syncthreads();
+  int blk = blockIdx.x;
+  if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int c = blk * kWave + (int)threadIdx.x;
+  if (c >= B4) return;
+  const int N = q.N;
+  vf4 mn = splat4(INFINITY), vs = splat4(0.0f);
+#pragma unroll 2
+  for (int k = 0; k < N; ++k) {
+    const vf4 px = lane_ld4(X + (size_t)(3 * k + 0) * ld4 + c), py = lane_ld4(X + (size_t)(3 * k + 1) * ld4 + c),
+              pz = lane_ld4(X + (size_t)(3 * k + 2) * ld4 + c);
+    for (int j = 0; j < K; ++j) {
+      const vf4 dx = px - sph[4 * j + 0], dy = py - sph[4 * j + 1], dz = pz - sph[4 * j + 2];
+      const vf4 cj = (dx * dx + dy * dy + dz * dz) - sph[4 * j + 3];
+      lane_st4(C + (size_t)(k * K + j) * ld4 + c, cj);
+      for (int w = 0; w < 4; ++w) { mn[w] = fminf(mn[w], cj[w]); vs[w] += fmaxf(0.0f, -cj[w]); }
+    }
+  }
+  if (cmin != nullptr) cmin[c] = mn;
+  if (viol != nullptr) viol[c] = vs;
+}
+
 constexpr int kLaneBlock = 64;   // one wavefront per workgroup: small batches still spread over CUs
 
 template <typename R>
@@ -1420,6 +1504,14 @@ int init_impl(const se3mpc_params* p, int B, int ld, const R* p0, const R* v0, c
   if (rc) return rc;
   if (B == 0) return SE3MPC_OK;
   if (!p0 || !v0 || !X0 || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
+  if constexpr (sizeof(R) == 4) {
+    if (wide_ok(B, ld, {p0, v0, goal, X0})) {
+      hipLaunchKernelGGL(init4_kernel, dim3(grid_for(B / 4, kWave)), dim3(192), 0, (hipStream_t)stream, make_dev_params<float>(*p), B / 4, ld / 4,
+                         reinterpret_cast<const vf4*>(p0), reinterpret_cast<const vf4*>(v0), reinterpret_cast<const vf4*>(goal), project,
+                         reinterpret_cast<vf4*>(X0));
+      return launch_status("se3mpc_init");
+    }
+  }
   hipLaunchKernelGGL(init_kernel<R>, dim3(grid_for(B, kWave)), dim3(192), 0, (hipStream_t)stream,
                      make_dev_params<R>(*p), B, ld, p0, v0, goal, project, X0);
   return launch_status("se3mpc_init");
@@ -1464,9 +1556,18 @@ int obstacle_residual_impl(const se3mpc_params* p, int B, int ld, const R* X, co
   if (C == nullptr)
     hipLaunchKernelGGL(obstacle_reduce_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
                        make_dev_params<R>(*p), B, ld, X, spheres, K, cmin, viol);
-  else
+  else {
+    if constexpr (sizeof(R) == 4) {
+      if (wide_ok(B, ld, {X, C, cmin, viol})) {
+        hipLaunchKernelGGL(obstacle_residual4_kernel, dim3(grid_for(B / 4, kLaneBlock)), dim3(kLaneBlock), 0, (hipStream_t)stream,
+                           make_dev_params<float>(*p), B / 4, ld / 4, reinterpret_cast<const vf4*>(X), spheres, K, reinterpret_cast<vf4*>(C),
+                           reinterpret_cast<vf4*>(cmin), reinterpret_cast<vf4*>(viol));
+        return launch_status("se3mpc_obstacle_residual");
+      }
+    }
     hipLaunchKernelGGL(obstacle_residual_kernel<R>, dim3(grid_for(B, kLaneBlock)), dim3(kLaneBlock), 0,
                        (hipStream_t)stream, make_dev_params<R>(*p), B, ld, X, spheres, K, C, cmin, viol);
+  }
   return launch_status("se3mpc_obstacle_residual");
 }
 
@@ -1859,8 +1960,9 @@ extern "C" int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int 
 }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant >= 384 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
-  se3mpc::g_rollout_variant = variant;
+  if (variant < 0 || variant >= 1536 || ((variant >> 7) & 3) == 3 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
+  se3mpc::g_rollout_variant = variant & 511;
+  se3mpc::g_wide_select = variant >> 9;
   return SE3MPC_OK;
 }
 

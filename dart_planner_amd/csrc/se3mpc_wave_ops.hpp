@@ -163,6 +163,12 @@ __device__ __forceinline__ void lane_st(const LaneBuf<double>& b, unsigned voff,
   __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), b.rsrc, voff, soff, AUX);
 }
 
+// ---- 16 bytes per lane: four consecutive trajectories of one row (streaming kernels at saturating batches, eval_kernels.hip)
+typedef float vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ vf4 lane_ld4(const vf4* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void lane_st4(vf4* p, vf4 v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ vf4 splat4(float x) { return (vf4)(x); }
+
 // Tell the compiler a value is the same in every lane (moves it to an SGPR).
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

@@ -243,7 +243,9 @@ int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uin
  * else 3).  variant + 8 * (flags + 1) forces the memory-policy
  * flags of the benchmarked instantiation (horizon 30, f32, gradient): bit 0 nt loads, bit 1 nt stores,
  * bit 2 XCD-contiguous block order; the default is all three (7).  + 128 / + 256 forces the workgroup of
- * se3mpc_rollout_obstacles_* to 3 / 8 wavefronts (default: 8 while 8 x workgroups <= 1024, else 3).
+ * se3mpc_rollout_obstacles_* to 3 / 8 wavefronts (default: 8 while 8 x workgroups <= 1024, else 3).  + 512 / + 1024: the
+ * write-heavy float32 lane kernels never / always take their 16-byte-per-lane form (four trajectories per lane; needs B and ld
+ * multiples of 4 and 16-byte aligned operands; default: from 262144 trajectories up).
  * All compute the same quantities. */
 int se3mpc_set_rollout_variant(int variant);
 

@@ -50,4 +50,23 @@ inline void lane_st(const LaneBuf<R>& b, unsigned voff, unsigned soff, R v) {
 inline int wave_uniform(int v) { return v; }
 inline int lane_id() { return (int)(threadIdx.x & 63u); }
 
+
+// ---- 16 bytes per lane (product header: a clang ext_vector_type + non-temporal builtins)
+struct vf4 {
+  float v[4];
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+};
+#define SE3MPC_EMU_VF4_OP(OP)                                                                                         \
+  inline vf4 operator OP(const vf4& a, const vf4& b) { vf4 r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+  inline vf4 operator OP(float a, const vf4& b) { vf4 r; for (int i = 0; i < 4; ++i) r.v[i] = a OP b.v[i]; return r; }        \
+  inline vf4 operator OP(const vf4& a, float b) { vf4 r; for (int i = 0; i < 4; ++i) r.v[i] = a.v[i] OP b; return r; }
+SE3MPC_EMU_VF4_OP(+)
+SE3MPC_EMU_VF4_OP(-)
+SE3MPC_EMU_VF4_OP(*)
+SE3MPC_EMU_VF4_OP(/)
+#undef SE3MPC_EMU_VF4_OP
+inline vf4 lane_ld4(const vf4* p) { return *p; }
+inline void lane_st4(vf4* p, vf4 v) { *p = v; }
+inline vf4 splat4(float x) { return vf4{{x, x, x, x}}; }
 }  // namespace se3mpc

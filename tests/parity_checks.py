@@ -70,6 +70,39 @@ def random_batch(rng, B, N, spread=2.0):
     return p0, v0, goal, T
 
 
+def check_wide_kernels(h: Harness, N: int, B: int, seed: int = 0, K: int = 7):
+    """The 16-byte-per-lane forms of the write-heavy float32 lane kernels (four trajectories per lane; taken by default from 262144
+    trajectories up, forced here with se3mpc_set_rollout_variant(+1024)) give the SAME BITS as the dword forms (+512), and fall back to them
+    when the batch is not a multiple of 4."""
+    assert h.dt == np.float32 and B % 4 == 0
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N)
+    p0, v0, goal, T = random_batch(rng, B, N)
+    X = np.concatenate([rng.uniform(-30, 30, (B, 3 * N)), rng.uniform(-15, 15, (B, 3 * N)), T.reshape(B, -1)], axis=1)
+    S = np.concatenate([rng.uniform(-10, 10, (K, 3)), rng.uniform(0.3, 2.0, (K, 1))], axis=1)
+    lib = h.ops.lib
+
+    def run(Bx):
+        sl = slice(0, Bx)
+        a = [h.to_host(h.ops.init(prm, h.lane(p0[sl], Bx), h.lane(v0[sl], Bx), h.lane(goal[sl], Bx), project=pj)) for pj in (False, True)]
+        a += [h.to_host(x) for x in h.ops.obstacle_residual(prm, h.lane(X[sl], Bx), h.to_dev(S.astype(h.dt)))]
+        return a
+    try:
+        lib.set_rollout_variant(512)
+        narrow = run(B)
+        lib.set_rollout_variant(1024)
+        wide = run(B)
+        odd = run(B - 1)                                 # not a multiple of 4: the dword kernels, whatever the switch says
+        lib.set_rollout_variant(512)
+        odd_ref = run(B - 1)
+    finally:
+        lib.set_rollout_variant(0)
+    for w, n in zip(wide, narrow):
+        assert np.array_equal(w, n)
+    for w, n in zip(odd, odd_ref):
+        assert np.array_equal(w, n)
+
+
 # --------------------------------------------------------------------------------------- lane kernels
 def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,), dt=None):
     rng = np.random.default_rng(seed)

@@ -184,6 +184,10 @@ def test_control_fast_reproduces_reference_sequences(emu_ops, golden_controller,
     cc.check_fast_batch_vs_oracle(harness(emu_ops, dt), B=70, calls=6, seed=5)
 
 
+def test_wide_lane_kernels_equal_the_dword_forms(emu_ops):
+    pc.check_wide_kernels(harness(emu_ops, np.float32), N=6, B=132, seed=3)
+
+
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
 def test_controller_building_blocks(emu_ops, dt):
     cc.check_building_blocks(harness(emu_ops, dt), B=60, seed=7)

@@ -408,6 +408,13 @@ def test_wave_ops_selftest(gpu_ops):
         assert ops.decode_key(key)[0] == pos == int(torch.argmin(cost))
 
 
+def test_wide_lane_kernels_equal_the_dword_forms(gpu_ops):
+    """16 bytes per lane (four trajectories) for the write-heavy float32 streams == the dword kernels bit for bit, forced at small sizes and by
+    default at a saturating batch."""
+    pc.check_wide_kernels(harness(gpu_ops, np.float32), N=30, B=4096, seed=5, K=16)
+    pc.check_wide_kernels(harness(gpu_ops, np.float32), N=50, B=1028, seed=6, K=3)
+
+
 def test_planner_shooting_plan(gpu_ops):
     """SE3MPCPlanner.plan_shooting: 8192 thrust samples x 16 iterations in one launch, argmin, rollout and extraction of the winner.  The
     winner's thrust sequence is what the host-chained oracle produces from the same sample, the Trajectory satisfies the reference's dynamics
