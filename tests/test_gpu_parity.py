@@ -408,6 +408,25 @@ def test_wave_ops_selftest(gpu_ops):
         assert ops.decode_key(key)[0] == pos == int(torch.argmin(cost))
 
 
+def test_planner_shooting_plan_shapes(gpu_ops):
+    """The captured plan_shooting over odd sample counts (1, not a multiple of 64, one more than a multiple), zero iterations, both precisions and
+    three horizons: the same winner and thrust sequence as the eager chain of the same launches; at most four captured graphs are kept."""
+    from dart_planner_amd.common.types import DroneState
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCConfig, SE3MPCPlanner
+    from dart_planner_amd.distributed import sharded_shooting_plan
+    st = DroneState(timestamp=0.0, position=np.array([0.3, -0.2, 1.0]), velocity=np.array([0.1, 0.0, -0.2]))
+    goal = np.array([2.0, 1.0, 2.5])
+    for N in (6, 30, 50):
+        pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N), precision="f64")
+        pl._ops = gpu_ops
+        for S, K, prec in ((1, 0, "f32"), (100, 3, "f32"), (4097, 5, "f64"), (64, 1, "f64"), (65, 2, "f32")):
+            tr = pl.plan_shooting(st, goal, n_samples=S, iters=K, step=0.5, sigma=1.0, seed=2, precision=prec)
+            e = sharded_shooting_plan(gpu_ops, pl._params(), st.position, st.velocity, goal, S, K, 0.5, 1.0, 2, prec)
+            assert e["sample"] == pl.last_result["sample"] and np.array_equal(e["T"], pl.last_result["T"]), (N, S, K, prec)
+            assert np.all(np.isfinite(tr.positions)) and tr.positions.shape == (N, 3)
+        assert len(pl._shooting_graphs) == 4
+
+
 def test_wide_lane_kernels_equal_the_dword_forms(gpu_ops):
     """16 bytes per lane (four trajectories) for the write-heavy float32 streams == the dword kernels bit for bit, forced at small sizes and by
     default at a saturating batch."""
