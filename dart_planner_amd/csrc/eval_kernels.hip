@@ -384,19 +384,28 @@ __device__ __forceinline__ void attitude_step(const R t[3], R inv_dt, AttitudeSt
   att[0] = att[1] = att[2] = (R)0;
   rate[0] = rate[1] = rate[2] = (R)0;
   if (!(mag > (R)1e-6)) return;                                        // planner.py:619, :651-653
-  R b3[3] = {t[0] / mag, t[1] / mag, t[2] / mag};                      // planner.py:621
+  // float32: one reciprocal and three products per normalisation instead of three IEEE quotients (1 ulp; this kernel was VALU co-bound:
+  // 273 instructions per step, 60 % VALU-busy at 1 M trajectories); float64 keeps the quotients
+  R b3[3], b1[3];
+  if constexpr (sizeof(R) == 4) { const R rm = rcp_approx(mag); b3[0] = t[0] * rm; b3[1] = t[1] * rm; b3[2] = t[2] * rm; }
+  else { b3[0] = t[0] / mag; b3[1] = t[1] / mag; b3[2] = t[2] / mag; }   // planner.py:621
   // b1 = (1,0,0) x b3 = (0, -b3z, b3y)                                // planner.py:625-626
-  R b1[3] = {(R)0, -b3[2], b3[1]};
+  b1[0] = (R)0; b1[1] = -b3[2]; b1[2] = b3[1];
   const R n1 = sqrt(b1[1] * b1[1] + b1[2] * b1[2]);                    // planner.py:627
-  if (n1 > (R)1e-6) { b1[1] /= n1; b1[2] /= n1; }                      // planner.py:628-629
-  else { b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0; }                   // planner.py:630-631
+  const bool regular = n1 > (R)1e-6;
+  if (regular) {                                                       // planner.py:628-629
+    if constexpr (sizeof(R) == 4) { const R rn = rcp_approx(n1); b1[1] *= rn; b1[2] *= rn; }
+    else { b1[1] /= n1; b1[2] /= n1; }
+  } else { b1[0] = (R)1; b1[1] = (R)0; b1[2] = (R)0; }                 // planner.py:630-631
   const R b2[3] = {b3[1] * b1[2] - b3[2] * b1[1],                      // planner.py:632
                    b3[2] * b1[0] - b3[0] * b1[2],
                    b3[0] * b1[1] - b3[1] * b1[0]};
   // R = [b1 b2 b3] (columns).  roll = atan2(R21, R22), pitch = asin(-R20), yaw = atan2(R10, R00)
   att[0] = atan2(b2[2], b3[2]);                                        // planner.py:636
   att[1] = asin(fmin(fmax(-b1[2], (R)-1), (R)1));                      // planner.py:637 (clamped: rounding can leave |R20| 1 ulp above 1)
-  att[2] = atan2(b1[1], b1[0]);                                        // planner.py:638
+  // yaw = atan2(b1y, b1x) (planner.py:638) with b1x exactly 0 (regular) or b1 = (1,0,0): +-pi/2 with the sign of b1y (a signed zero stays a
+  // signed zero), or 0 -- what atan2 returns there, without evaluating it
+  att[2] = regular ? (b1[1] == (R)0 ? b1[1] : copysign((R)1.5707963267948966, b1[1])) : (R)0;
   if (prev.valid) {                                                    // planner.py:641-649
     // omega = R^T (R - R_prev)/dt ; rates = (omega[2][1], omega[0][2], omega[1][0])
     R d1[3], d2[3], d3[3];
@@ -447,7 +456,10 @@ extract_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ T, R* __rest
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
           const unsigned r = (unsigned)(3 * k + a) * rowb;
-          if (acc != nullptr) lane_st<2>(lane_buf(acc), voff, r, (R)(t[a] / q.mass - ((a == 2) ? q.grav : (R)0)));   // planner.py:589
+          if (acc != nullptr) {                                                                                       // planner.py:589
+            const R am = sizeof(R) == 4 ? t[a] * q.inv_mass : t[a] / q.mass;
+            lane_st<2>(lane_buf(acc), voff, r, (R)(am - ((a == 2) ? q.grav : (R)0)));
+          }
           if (att != nullptr) lane_st<2>(lane_buf(att), voff, r, at[a]);
           if (rates != nullptr) lane_st<2>(lane_buf(rates), voff, r, rt[a]);
         }

@@ -169,6 +169,10 @@ __device__ __forceinline__ vf4 lane_ld4(const vf4* p) { return __builtin_nontemp
 __device__ __forceinline__ void lane_st4(vf4* p, vf4 v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ vf4 splat4(float x) { return (vf4)(x); }
 
+// 1 / x: one v_rcp_f32 (1 ulp) for float where a kernel's float32 tolerance allows it, the IEEE quotient for double
+__device__ __forceinline__ float rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ double rcp_approx(double x) { return 1.0 / x; }
+
 // Tell the compiler a value is the same in every lane (moves it to an SGPR).
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 

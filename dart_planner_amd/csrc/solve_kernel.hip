@@ -1305,7 +1305,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     b2[2] = b3[0] * b1[1] - b3[1] * b1[0];
     roll = atan2(b2[2], b3[2]);
     pitch = asin(fmin(fmax(-b1[2], -1.0), 1.0));
-    yaw = atan2(b1[1], b1[0]);
+    yaw = n1 > 1e-6 ? (b1[1] == 0.0 ? b1[1] : copysign(1.5707963267948966, b1[1])) : 0.0;   // atan2(b1y, b1x) with b1x exactly 0, or b1 = (1,0,0)
   }
   for (int c = 0; c < 3; ++c) { Rm[c * kWave + lane] = b1[c]; Rm[(3 + c) * kWave + lane] = b2[c]; Rm[(6 + c) * kWave + lane] = b3[c]; }
   __syncthreads();

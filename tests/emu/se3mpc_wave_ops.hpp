@@ -66,6 +66,8 @@ SE3MPC_EMU_VF4_OP(-)
 SE3MPC_EMU_VF4_OP(*)
 SE3MPC_EMU_VF4_OP(/)
 #undef SE3MPC_EMU_VF4_OP
+inline float rcp_approx(float x) { return 1.0f / x; }
+inline double rcp_approx(double x) { return 1.0 / x; }
 inline vf4 lane_ld4(const vf4* p) { return *p; }
 inline void lane_st4(vf4* p, vf4 v) { *p = v; }
 inline vf4 splat4(float x) { return vf4{{x, x, x, x}}; }
