@@ -101,6 +101,20 @@ def check_wide_kernels(h: Harness, N: int, B: int, seed: int = 0, K: int = 7):
         assert np.array_equal(w, n)
     for w, n in zip(odd, odd_ref):
         assert np.array_equal(w, n)
+    # a batch shorter than the leading dimension (B < ld, both multiples of 4): columns B.. of the outputs are not written
+    ld, Bs = B, B - 8
+    try:
+        outs = []
+        for var in (512, 1024):
+            lib.set_rollout_variant(var)
+            pl, vl, gl = h.lane(p0, ld), h.lane(v0, ld), h.lane(goal, ld)
+            X0 = h.ops.init(prm, pl, vl, gl, B=Bs)
+            Cm, cm, vi = h.ops.obstacle_residual(prm, h.lane(X, ld), h.to_dev(S.astype(h.dt)), B=Bs)
+            outs.append([h.to_host(a)[..., :Bs] for a in (X0, Cm, cm, vi)])
+    finally:
+        lib.set_rollout_variant(0)
+    for w, n in zip(outs[1], outs[0]):
+        assert np.array_equal(w, n)
 
 
 # --------------------------------------------------------------------------------------- lane kernels
