@@ -92,6 +92,75 @@ def test_controller_mirror_fast_path(gpu_ops, golden_controller):
     assert th == 1.0 * 9.80665 and not tq.any()
 
 
+def test_controller_mirror_private_steps(gpu_ops):
+    """The mirror's private steps on the device, with the situations and known answers of the reference's own controller tests
+    (tests/test_controller_torque_calculation.py:20-92, :157-176; tests/control/test_geometric_controller_anti_windup.py:44-75, :96-130, :199-214;
+    tests/control/test_geometric_controller_yaw_singularity.py:32-66, :79-96, :215-233) -- those files themselves run in place on the CPU box."""
+    from dart_planner_amd.control.geometric_controller import GeometricController, GeometricControllerConfig
+    from dart_planner_amd.common.types import DroneState
+
+    def make(**kw):
+        cfg = GeometricControllerConfig()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        c = GeometricController(config=cfg, tuning_profile="")
+        c._ops = gpu_ops
+        return c
+    # torque = w x (I w) with zero attitude gains: diagonal inertia, then a full matrix assigned to _fast_inertia
+    c = make(inertia=np.array([0.025, 0.03, 0.045]), max_torque_xyz=np.array([100.0, 100.0, 100.0]), kp_att=np.zeros(3), kd_att=np.zeros(3))
+    w = np.array([0.1, 0.2, 0.3])
+    tq = c._fast_geometric_attitude_control(att=np.zeros(3), ang_vel=w, b3_des=np.array([0, 0, 1]), yaw_des=0.0, yaw_rate_des=0.0)
+    np.testing.assert_allclose(tq, np.cross(w, np.array([0.0025, 0.006, 0.0135])), rtol=1e-10)
+    full = np.array([[0.02, 0.001, 0.002], [0.001, 0.02, 0.003], [0.002, 0.003, 0.04]])
+    c._fast_inertia = full
+    tq = c._fast_geometric_attitude_control(np.zeros(3), w, np.array([0, 0, 1]), 0.0, 0.0)
+    np.testing.assert_allclose(tq, np.cross(w, full @ w), rtol=1e-10)
+    # the two attitude laws agree on a diagonal inertia; torque limits are applied and counted
+    c = make(inertia=np.array([0.025, 0.03, 0.045]))
+    st = DroneState(timestamp=0.0, position=np.zeros(3), velocity=np.zeros(3), attitude=np.zeros(3), angular_velocity=np.array([1.0, 2.0, 3.0]))
+    _, t_full = c._geometric_attitude_control(st, np.array([0, 0, 1]), 0.0, 0.0, 10.0, 0.01)
+    t_fast = c._fast_geometric_attitude_control(np.zeros(3), np.array([1.0, 2.0, 3.0]), np.array([0, 0, 1]), 0.0, 0.0)
+    np.testing.assert_allclose(t_full, t_fast, rtol=1e-10)
+    c = make(max_torque_xyz=np.array([1.0, 1.0, 2.0]))
+    tq = c._fast_geometric_attitude_control(np.zeros(3), np.array([10.0, 10.0, 10.0]), np.array([0, 0, 1]), 0.0, 0.0)
+    assert np.all(np.abs(tq) <= np.array([1.0, 1.0, 2.0])) and c._torque_saturation_count == int(np.sum(np.abs(c.unsaturated_torque) > np.array([1.0, 1.0, 2.0])))
+    # per-axis integral clamp, clamping and back-calculation anti-windup with assigned members
+    aw = dict(kp_pos=np.array([10.0, 10.0, 12.0]), ki_pos=np.array([0.5, 0.5, 1.0]), kd_pos=np.array([6.0, 6.0, 8.0]), max_thrust=20.0, min_thrust=0.5,
+              max_integral_pos=5.0, max_integral_per_axis=np.array([2.0, 2.0, 3.0]), back_calculation_gain=0.1, integral_decay_factor=0.99, saturation_threshold=0.95)
+    c = make(**aw)
+    for _ in range(100):
+        c._update_integral_error(np.array([10.0, 10.0, 10.0]), 0.01)
+    assert np.all(np.abs(c.integral_vel_error) <= np.array([2.0, 2.0, 3.0]) + 1e-12)
+    c = make(**aw)
+    c._update_integral_error(np.array([1.0, 1.0, 1.0]), 0.01)
+    free = c.integral_vel_error.copy()
+    c.integral_vel_error = np.zeros(3)
+    c._update_integral_error(np.array([1.0, 1.0, 1.0]), 0.01, thrust_saturated=True)
+    np.testing.assert_allclose(c.integral_vel_error, 0.1 * free, rtol=1e-12)              # clamping: the update shrinks tenfold (controller.py:590-591)
+    c = make(anti_windup_method="back_calculation", **aw)
+    c.unsaturated_thrust = 25.0
+    c.unsaturated_torque = np.array([6.0, 3.0, 3.0])
+    c._update_integral_error(np.array([1.0, 1.0, 1.0]), 0.01, thrust_saturated=True, torque_saturated=np.array([True, False, False]))
+    mt = np.asarray(c.config.max_torque_xyz, float)
+    exp = np.array([0.01, 0.01, 0.01]) - (25.0 - 20.0) * 0.1 * np.array([0.33, 0.33, 0.34]) - np.array([(6.0 - mt[0]) * 0.1 * 0.5, 0.0, 0.0])
+    np.testing.assert_allclose(c.integral_vel_error, exp, rtol=1e-12, atol=1e-15)
+    assert abs(c.unsaturated_thrust - 25.0) == 0.0 and not c.last_thrust_saturated
+    c.last_thrust_saturated = True; c.last_torque_saturated = np.array([True, False, True])
+    assert c.last_thrust_saturated and c.last_torque_saturated.tolist() == [True, False, True]
+    # yaw singularity: detection values and the fallbacks' orthonormal frames
+    c = make()
+    up = np.array([0.0, 0.0, 1.0])
+    for z, sing in ((0.0, False), (0.95, True), (-0.95, True), (0.5, True), (0.1, True), (0.09, False)):
+        s_, ca, method = c._detect_yaw_singularity(np.array([0.0, 0.0, z]), up)
+        assert (s_, ca, method) == (sing, abs(z), "skip_yaw")
+    c.config.default_heading_yaw = np.pi / 2
+    for method, b3 in (("skip_yaw", np.array([0.1, 0.1, 0.99])), ("default_heading", up), ("maintain_current", np.array([0.1, 0.0, 0.995])), ("unknown_method", up)):
+        b3 = b3 / np.linalg.norm(b3)
+        b1, b2, b3o = c._handle_yaw_singularity(np.array([1.0, 0.0, 0.0]), b3, np.pi / 4, method)
+        Rm = np.stack([b1, b2, b3o], 1)
+        assert np.allclose(b3o, b3) and np.allclose(Rm.T @ Rm, np.eye(3), atol=1e-12), method
+
+
 def test_closed_loop_reproduces_reference_loops(gpu_ops, golden_controller):
     data, meta = golden_controller
     worst = cc.check_closed_loops_golden(harness(gpu_ops, np.float64), data, meta)
