@@ -533,7 +533,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   auto eval_fg = [&](bool with_gd = false) -> double {
     bool moved = false;
 #pragma unroll
-    for (int j = 0; j < J; ++j) moved = moved || !(x[j] == xlast[lane + kWave * j]);
+    for (int j = 0; j < J; ++j) moved = moved | !(x[j] == xlast[lane + kWave * j]);   // | not ||: per-lane flags accumulate without divergent branches
     if (wave_ballot(moved) != 0ull) {
       ++nfev;
 #pragma unroll
@@ -637,12 +637,19 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         const double dj = moving ? neggi : 0.0;
         d[j] = dj;
         f1p -= dj * dj;
-        const bool brk = moving && neggi != 0.0;          // one division: tl / (-neggi) for a descending, tu / neggi for an ascending variable
-        const double quot = (neggi < 0.0 ? tl : tu) / fabs(neggi);
-        tbp[j] = brk ? quot : kInf;
+        // breakpoint t_j = num / |g_j| (tl / (-neggi) for a descending, tu / neggi for an ascending variable).  Only the numerator is kept here:
+        // the quotient is formed where a breakpoint's VALUE is needed -- never on the first iterate (theta = 1: t_j <= 1 <=> num <= |g_j|, exactly)
+        // and not on an iterate whose Cauchy point lies before every breakpoint, which a product decides (below): the common case
+        const bool brk = moving & (neggi != 0.0);
+        tbp[j] = brk ? (neggi < 0.0 ? tl : tu) : kInf;
         nbr += brk ? 1 : 0;
         z[j] = x[j];
       }
+      // tbp[] holds numerators until this turns them into breakpoints (six f64 divisions per lane)
+      auto breakpoints = [&]() {
+#pragma unroll
+        for (int j = 0; j < J; ++j) tbp[j] = tbp[j] / fabs(g[j]);            // +inf / |g| stays +inf (|g| is finite); brk implies g != 0
+      };
       SE3MPC_TICK(8)
       if (col == 0 && !q.seq_cauchy) {
         // No L-BFGS pairs yet: B = theta*I and the piecewise quadratic along the projected path is
@@ -654,11 +661,15 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         // the first iterate), so they are taken in one parallel pass instead of 170 wavefront reductions.
         if (sbgnrm > 0.0) {
           const double tstar = 1.0 / theta;
+          const bool unit = theta == 1.0;                                  // the first iterate of every solve
+          if (!unit) breakpoints();
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             double lo, hi;
             slot_bounds<J>(q, j, code[j], lo, hi);
-            const bool hit = iwhere[j] == 0 && tbp[j] <= tstar;          // d is 0 wherever iwhere != 0: z + tstar*d leaves those alone
+            // fl(num / |g|) <= 1 <=> num <= |g| (rounding is monotone and fl(1) = 1): no quotient while theta is 1
+            const bool reached = unit ? tbp[j] <= fabs(g[j]) : tbp[j] <= tstar;
+            const bool hit = iwhere[j] == 0 && reached;                    // d is 0 wherever iwhere != 0: z + tstar*d leaves those alone
             const bool upw = d[j] > 0.0;
             z[j] = hit ? (upw ? hi : lo) : z[j] + tstar * d[j];
             iwhere[j] = hit ? (upw ? 2 : 1) : iwhere[j];
@@ -715,7 +726,17 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           double dtm = -f1 / f2, tsum = 0.0, tj = 0.0;
           int nleft = nbreak;
           bool all_fixed = false;
-          while (nleft > 0) {
+          // The search below stops before its first crossing when dtm < min_j t_j.  num * (1 - 2^-50) > dtm * |g| (both products rounded) implies
+          // num / |g| > dtm * (1 + 2^-51), hence fl(num / |g|) > dtm: if that holds in every lane the loop would do nothing but form the six
+          // quotients per lane and their wavefront minimum -- skipped.  Otherwise (a crossing, or too close to call) the published search runs.
+          // (accumulated with `&`: as a short-circuit `&&` chain this became nine nested divergent regions, and the J = 9 float32 kernel, whose
+          // register spills to AGPRs landed inside them, then returned a wrong Cauchy point on the GPU -- found by the golden solves, N = 50)
+          bool clear = dtm > 0.0;
+#pragma unroll
+          for (int j = 0; j < J; ++j) clear = clear & (tbp[j] * 0.99999999999999911182158029987 > dtm * fabs(g[j]));   // & not &&: straight-line compares
+          const bool skip_search = wave_ballot(!clear) == 0ull;
+          if (!skip_search) breakpoints();
+          while (!skip_search && nleft > 0) {
             // next smallest breakpoint: per-lane min, DPP min, owner = first lane holding it
             double tmin = tbp[0];
             int jm = 0;
@@ -1027,7 +1048,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             const double xk = fmin(hi, fmax(lo, z[j] + dn));
             d[j] = fr ? dn : d[j];
             z[j] = fr ? xk : z[j];
-            hitp = hitp || (fr && (xk == lo || xk == hi));
+            hitp = hitp | (fr & ((xk == lo) | (xk == hi)));
             ddp += (z[j] - x[j]) * g[j];
           }
           const bool iword = wave_ballot(hitp) != 0ull;
@@ -1091,8 +1112,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         const double a1 = d[j];
         const bool neg = a1 < 0.0, pos = a1 > 0.0;
         const double a2 = neg ? lo - x[j] : hi - x[j];
-        const bool blocked = neg ? a2 >= 0.0 : (pos && a2 <= 0.0);
-        const bool tighter = neg ? a1 * smx < a2 : (pos && a1 * smx > a2);
+        const bool blocked = neg ? a2 >= 0.0 : (pos & (a2 <= 0.0));
+        const bool tighter = neg ? a1 * smx < a2 : (pos & (a1 * smx > a2));
         const double quot = a2 / a1;
         smx = blocked ? 0.0 : (tighter ? quot : smx);
       }

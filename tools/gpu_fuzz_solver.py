@@ -48,12 +48,21 @@ def sweep(h, N, B, seed, **ov):
 
 tot = dict(problems=0, count_mismatches=0, worst_f64=0.0, worst_f32=0.0, worst_on_count_mismatch=0.0)
 t0 = time.time()
+# the published sequential Cauchy search (se3mpc_set_solver_variant(1)) at the three register-slot counts (J = 3, 6, 9)
+configs += [(N, dict(_solver_variant=1)) for N in (20, 30, 50, 64)]
 for i, (N, ov) in enumerate(configs):
+    ov = dict(ov)
+    variant = ov.pop("_solver_variant", 0)
     for dt, key in ((np.float64, "worst_f64"), (np.float32, "worst_f32")):
-        ws, wd, mism = sweep(harness(dt), N, B, 1000 + 17 * i, **ov)
+        ops.lib.set_solver_variant(variant)
+        try:
+            ws, wd, mism = sweep(harness(dt), N, B, 1000 + 17 * i, **ov)
+        finally:
+            ops.lib.set_solver_variant(0)
+        ov_print = dict(ov, solver_variant=variant) if variant else ov
         tot["problems"] += B; tot["count_mismatches"] += len(mism); tot[key] = max(tot[key], ws)
         tot["worst_on_count_mismatch"] = max(tot["worst_on_count_mismatch"], wd)
-        print(json.dumps(dict(horizon=N, options=ov, dtype=np.dtype(dt).name, problems=B, iteration_count_mismatches=len(mism),
+        print(json.dumps(dict(horizon=N, options=ov_print, dtype=np.dtype(dt).name, problems=B, iteration_count_mismatches=len(mism),
                               max_position_error_m=ws, mismatched=mism[:8])), flush=True)
 tot["seconds"] = round(time.time() - t0, 1)
 print(json.dumps(tot))
