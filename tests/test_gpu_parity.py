@@ -160,6 +160,19 @@ def test_batched_solve_matches_scipy_problem_by_problem(gpu_ops, N, B):
         assert mismatch <= (0.0 if dt == np.float64 else 0.02)
 
 
+@pytest.mark.parametrize("N,B", [(20, 64), (30, 96), (50, 64), (64, 48)])
+def test_batched_solve_published_cauchy_search_matches_scipy(gpu_ops, N, B):
+    """The published sequential Cauchy search (se3mpc_set_solver_variant(1)) at the three register-slot counts (J = 3, 6, 9), both dtypes,
+    problem by problem against SciPy -- the J = 9 float32 kernel once returned a wrong Cauchy point under this variant only."""
+    gpu_ops.lib.set_solver_variant(1)
+    try:
+        for dt, tol in ((np.float64, 1e-9), (np.float32, 1e-4)):
+            worst, mismatch = pc.check_solver_vs_oracle(harness(gpu_ops, dt), N, B, seed=100 + N)
+            assert worst <= tol and mismatch <= (0.0 if dt == np.float64 else 0.02), (N, np.dtype(dt).name, worst, mismatch)
+    finally:
+        gpu_ops.lib.set_solver_variant(0)
+
+
 def test_batched_solve_tight_tolerances(gpu_ops):
     """Many L-BFGS-B iterations per problem (memory fills up, line searches fail on the reference's
     inconsistent gradient): f64 must follow SciPy exactly."""
