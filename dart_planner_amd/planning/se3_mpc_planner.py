@@ -128,7 +128,9 @@ class SE3MPCPlanner(BasePlanner):
                 max_iterations=c.max_iterations, pgtol=c.convergence_tolerance, ftol=10 * c.convergence_tolerance,
                 has_goal=has_goal)
             self._params_sig = sig
-        return self._params_cached.copy(**overrides) if overrides else self._params_cached
+        if overrides and any(getattr(self._params_cached, k) != v for k, v in overrides.items()):
+            return self._params_cached.copy(**overrides)
+        return self._params_cached                            # (an override that repeats the cached value costs no copy: the per-plan path)
 
     # ------------------------------------------------------------------ planner.py:175-228
     def set_goal(self, goal_position) -> None:
@@ -221,6 +223,14 @@ class SE3MPCPlanner(BasePlanner):
                 io["d_out"] = ops.be.empty((nbytes,), "u8")
             io["h_in_np"] = io["h_in"].numpy()
             io["h_out_np"] = io["h_out"].numpy()
+            if mapped:
+                # the raw addresses of the per-plan call (se3mpc_solve_* on the pinned buffers), computed once per buffer set
+                esz = 4 if suf == "f32" else 8
+                o_x, o_acc, o_att, o_rates, o_thr, o_info, _ = ops._packed_offsets(B, N, esz)
+                pin, base, stepb = io["h_in"].data_ptr(), io["h_out"].data_ptr(), B * 3 * esz
+                io["ptr_in"] = (pin, pin + stepb, pin + 2 * stepb)
+                io["ptr_out"] = (base + o_x, base + o_info, base + o_acc, base + o_att, base + o_rates, base + o_thr)
+                io["ptr_x0"] = io["h_x0"].data_ptr()
         cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
         stream_handle = None if cur is None else cur.cuda_stream
         hin = io["h_in_np"]
@@ -232,7 +242,9 @@ class SE3MPCPlanner(BasePlanner):
             if x0 is not None:
                 io["h_x0_np"][...] = x0
                 hx0 = io["h_x0"]
-            ops.solve_packed(prm, io["h_in"], x0=hx0, out=io["h_out"], host_mapped=True, stream=stream_handle)
+            pin = io["ptr_in"]
+            ops.lib.call("solve", suf, B, pin[0], pin[1], pin[2] if prm.has_goal else 0, io["ptr_x0"] if hx0 is not None else 0, *io["ptr_out"],
+                         stream_handle, params=prm)         # = ops.solve_packed(host_mapped=True) without re-validating the same buffers every plan
         else:
             io["d_in"].copy_(io["h_in"], non_blocking=True)
             dx0 = None if x0 is None else torch.from_numpy(np.ascontiguousarray(x0)).to(device=dev, dtype=dt)
