@@ -708,10 +708,12 @@ class Ops:
         esz, dt = (4, np.float32) if suffix == "f32" else (8, np.float64)
         o_x, o_acc, o_att, o_rates, o_thr, o_info, end = self._packed_offsets(B, N, esz)
         raw = host_bytes[:end].copy()
-        if esz == 8:
-            f = lambda lo, cnt, shape: np.frombuffer(raw, dtype=dt, count=cnt, offset=lo).reshape(shape)
-        else:
-            f = lambda lo, cnt, shape: np.frombuffer(raw, dtype=dt, count=cnt, offset=lo).reshape(shape).astype(np.float64)
+        # the five float fields are one contiguous run: ONE view (f64) or ONE widening cast (f32), then slices of it
+        nfl = (o_thr + B * N * esz) // esz
+        allf = np.frombuffer(raw, dtype=dt, count=nfl)
+        if esz == 4:
+            allf = allf.astype(np.float64)
+        f = lambda lo, cnt, shape: allf[lo // esz:lo // esz + cnt].reshape(shape)
         return dict(x=f(o_x, B * 9 * N, (B, 9 * N)), accelerations=f(o_acc, B * 3 * N, (B, N, 3)),
                     attitudes=f(o_att, B * 3 * N, (B, N, 3)), body_rates=f(o_rates, B * 3 * N, (B, N, 3)),
                     thrusts=f(o_thr, B * N, (B, N)), info=np.frombuffer(raw, dtype=INFO_DTYPE, count=B, offset=o_info))
