@@ -540,10 +540,11 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
     goal = torch.rand(B, 3, device=dev, generator=g) * 40 - 20
     ts = []
     nfev = None
+    o = None
     for i in range(220):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        o = ops.solve(prm, p0, v0, goal)
+        o = ops.solve(prm, p0, v0, goal, out=o)             # steady state: the previous call's output tensors are written again
         torch.cuda.synchronize()
         if i >= 20:
             ts.append((time.perf_counter() - t0) * 1e3)

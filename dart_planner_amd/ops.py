@@ -626,10 +626,11 @@ class Ops:
         return out
 
     # ------------------------------------------------------------------ problem layout
-    def solve(self, params: Params, p0, v0, goal, x0=None, want_trajectory=True):
+    def solve(self, params: Params, p0, v0, goal, x0=None, want_trajectory=True, out=None):
         """a7 (+a3, a4, a11, a12): batched L-BFGS-B solve, one wavefront per problem.
         p0, v0, goal: (B, 3);  x0: (B, 9N) or None (reference cold start).  want_trajectory: True (all outputs), False (x and info only:
         restart sweeps) or "accelerations" (x, info, accelerations: the kernel skips attitudes / rates / thrust magnitudes).
+        out: a dict this method returned for the same shapes and output set -- its tensors are overwritten and returned (steady-state use).
         -> dict(x (B,9N), info (device bytes), acc/att/rates (B,N,3), thrust (B,N))."""
         N = params.horizon
         for a, nm in ((p0, "p0"), (v0, "v0")) + (((goal, "goal"),) if params.has_goal else ()):
@@ -642,14 +643,22 @@ class Ops:
             self.be.check(x0, "x0")
             if tuple(x0.shape) != (B, 9 * N) or self.be.suffix(x0) != suf:
                 raise ValueError(f"x0: expected ({B}, {9 * N}) {suf}")
-        X = self.be.empty((B, 9 * N), suf)
-        info = self.be.empty((B * INFO_DTYPE.itemsize,), "u8")
-        acc = att = rates = thrust = None
-        if want_trajectory == "accelerations":                # what a closed loop reading the plan in place needs next to x (se3mpc_closed_loop_*)
-            acc = self.be.empty((B, N, 3), suf)
-        elif want_trajectory:
-            acc, att, rates = (self.be.empty((B, N, 3), suf) for _ in range(3))
-            thrust = self.be.empty((B, N), suf)
+        if out is not None:
+            # steady state: the dict a previous call with the same shapes returned is written again (no allocations)
+            X, info, acc, att, rates, thrust = (out[k] for k in ("x", "info", "accelerations", "attitudes", "body_rates", "thrusts"))
+            if tuple(X.shape) != (B, 9 * N) or self.be.suffix(X) != suf or info.shape[0] != B * INFO_DTYPE.itemsize:
+                raise ValueError(f"out: buffers of another solve shape (expected x ({B}, {9 * N}) {suf})")
+            if (acc is None) != (not want_trajectory) or (att is None) != (want_trajectory is not True):
+                raise ValueError("out: buffers of another output set (want_trajectory)")
+        else:
+            X = self.be.empty((B, 9 * N), suf)
+            info = self.be.empty((B * INFO_DTYPE.itemsize,), "u8")
+            acc = att = rates = thrust = None
+            if want_trajectory == "accelerations":            # what a closed loop reading the plan in place needs next to x (se3mpc_closed_loop_*)
+                acc = self.be.empty((B, N, 3), suf)
+            elif want_trajectory:
+                acc, att, rates = (self.be.empty((B, N, 3), suf) for _ in range(3))
+                thrust = self.be.empty((B, N), suf)
         self.lib.call("solve", suf, B, self.be.ptr(p0), self.be.ptr(v0), self.be.ptr(goal if params.has_goal else None),
                       self.be.ptr(x0), self.be.ptr(X), self.be.ptr(info), self.be.ptr(acc), self.be.ptr(att),
                       self.be.ptr(rates), self.be.ptr(thrust), self.be.stream(), params=params)

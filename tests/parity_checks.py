@@ -485,6 +485,14 @@ def check_solver_extraction(h: Harness, N: int, B: int, seed: int = 3):
     assert oa["attitudes"] is None and oa["body_rates"] is None and oa["thrusts"] is None and ox["accelerations"] is None
     assert np.array_equal(h.to_host(oa["x"]), h.to_host(out["x"])) and np.array_equal(h.to_host(ox["x"]), h.to_host(out["x"]))
     assert np.array_equal(h.to_host(oa["accelerations"]), h.to_host(out["accelerations"]))
+    # steady state: writing a previous call's output tensors again gives the same bits, and another output set is refused
+    again = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal), x0=h.prob(X0), out=oa, want_trajectory="accelerations")
+    assert again["x"] is oa["x"] and np.array_equal(h.to_host(again["x"]), h.to_host(out["x"]))
+    try:
+        h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal), x0=h.prob(X0), out=oa)
+        raise AssertionError("an output dict of another output set was accepted")
+    except ValueError:
+        pass
     # cold start of the solver == a3 projected into the box (x0 = None path)
     out2 = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
     ref0 = orc.straight_line_init(p0.astype(h.dt).astype(float), v0.astype(h.dt).astype(float),
