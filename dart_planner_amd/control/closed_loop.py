@@ -35,8 +35,10 @@ class ClosedLoopMonteCarlo:
         st = ops.controller_state(self.controller, B)
         k = torch.arange(N, dtype=torch.float64, device=dev)
         logs = []
+        sol = None
         for c in range(cycles):
-            sol = ops.solve(prm, pos, vel, goal, want_trajectory=True if log else "accelerations")
+            # without logs every cycle writes the same plan tensors again (the closed-loop launch of a cycle is ordered before the next solve)
+            sol = ops.solve(prm, pos, vel, goal, want_trajectory=True if log else "accelerations", out=None if log else sol)
             stamps = (c * substeps * sim_dt) + k * prm.dt
             X = sol["x"]
             out = ops.closed_loop(self.controller, self.simulator, st, time, pos, vel, att, om, stamps, X, X[:, 3 * N:], sol["accelerations"],
