@@ -128,6 +128,136 @@ __device__ __forceinline__ float wave_bcast(float v, int src) {
 }
 __device__ __forceinline__ int wave_bcast(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 
+// ---- sub-wavefront groups: G = 8, 16, 32 or 64 consecutive lanes (aligned) work on one problem, 64 / G problems per wavefront ----
+// Every group operation below reads lanes of the caller's own group only, so groups may sit in different branches of divergent control
+// flow (each group's lanes are all active or all inactive together).  G <= 16: in-row DPP butterfly (quad_perm xor 1, xor 2,
+// row_half_mirror, row_mirror), after which every lane of the group holds the result.  G = 32: one more step across the two rows of a
+// half with gfx950's v_permlane16_swap_b32 (odd rows of one operand <-> even rows of the other: with both operands = v every lane ends
+// up with row0's value in one register and row1's in the other, in the same order for both rows, so both rows form bit-identical
+// results).  G = 64 is the whole-wavefront form above (v_readlane: the result is wave-uniform and lives in SGPRs).
+__device__ __forceinline__ void swap16_pair(uint32_t v, uint32_t& even_row, uint32_t& odd_row) {
+  const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  even_row = r[0]; odd_row = r[1];
+}
+// (a, b) = (value of the even row, value of the odd row) of the caller's 32-lane half, in every lane of the half
+__device__ __forceinline__ void swap16_f64(double v, double& a, double& b) {
+  const uint64_t x = (uint64_t)__double_as_longlong(v);
+  uint32_t alo, blo, ahi, bhi;
+  swap16_pair((uint32_t)x, alo, blo);
+  swap16_pair((uint32_t)(x >> 32), ahi, bhi);
+  a = __longlong_as_double((long long)(((uint64_t)ahi << 32) | alo));
+  b = __longlong_as_double((long long)(((uint64_t)bhi << 32) | blo));
+}
+
+template <int G>
+__device__ __forceinline__ double group_sum(double v) {
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "group size");
+  if constexpr (G == 64) return wave_sum(v);
+  v += dpp_f64<kDppQuadXor1>(v);
+  v += dpp_f64<kDppQuadXor2>(v);
+  v += dpp_f64<kDppRowHalfMirror>(v);
+  if constexpr (G >= 16) v += dpp_f64<kDppRowMirror>(v);
+  if constexpr (G >= 32) { double a, b; swap16_f64(v, a, b); v = a + b; }
+  return v;
+}
+template <int G, int K>
+__device__ __forceinline__ void group_sum_n(double (&v)[K]) {
+  if constexpr (G == 64) { wave_sum_n<K>(v); return; }
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppQuadXor1>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppQuadXor2>(v[k]);
+#pragma unroll
+  for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowHalfMirror>(v[k]);
+  if constexpr (G >= 16) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] += dpp_f64<kDppRowMirror>(v[k]);
+  }
+  if constexpr (G >= 32) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) { double a, b; swap16_f64(v[k], a, b); v[k] = a + b; }
+  }
+}
+template <int G>
+__device__ __forceinline__ double group_max(double v) {
+  if constexpr (G == 64) return wave_max(v);
+  v = fmax(v, dpp_f64<kDppQuadXor1>(v));
+  v = fmax(v, dpp_f64<kDppQuadXor2>(v));
+  v = fmax(v, dpp_f64<kDppRowHalfMirror>(v));
+  if constexpr (G >= 16) v = fmax(v, dpp_f64<kDppRowMirror>(v));
+  if constexpr (G >= 32) { double a, b; swap16_f64(v, a, b); v = fmax(a, b); }
+  return v;
+}
+template <int G>
+__device__ __forceinline__ double group_min(double v) {
+  if constexpr (G == 64) return wave_min(v);
+  v = fmin(v, dpp_f64<kDppQuadXor1>(v));
+  v = fmin(v, dpp_f64<kDppQuadXor2>(v));
+  v = fmin(v, dpp_f64<kDppRowHalfMirror>(v));
+  if constexpr (G >= 16) v = fmin(v, dpp_f64<kDppRowMirror>(v));
+  if constexpr (G >= 32) { double a, b; swap16_f64(v, a, b); v = fmin(a, b); }
+  return v;
+}
+template <int G>
+__device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+  if constexpr (G == 64) return wave_min_u32(v);
+  auto mn = [](uint32_t a, uint32_t b) { return a < b ? a : b; };
+  v = mn(v, dpp_u32<kDppQuadXor1>(v));
+  v = mn(v, dpp_u32<kDppQuadXor2>(v));
+  v = mn(v, dpp_u32<kDppRowHalfMirror>(v));
+  if constexpr (G >= 16) v = mn(v, dpp_u32<kDppRowMirror>(v));
+  if constexpr (G >= 32) { uint32_t a, b; swap16_pair(v, a, b); v = mn(a, b); }
+  return v;
+}
+template <int G>
+__device__ __forceinline__ int group_sum_i32(int v) {
+  if constexpr (G == 64) return wave_sum_i32(v);
+  v += (int)dpp_u32<kDppQuadXor1>((uint32_t)v);
+  v += (int)dpp_u32<kDppQuadXor2>((uint32_t)v);
+  v += (int)dpp_u32<kDppRowHalfMirror>((uint32_t)v);
+  if constexpr (G >= 16) v += (int)dpp_u32<kDppRowMirror>((uint32_t)v);
+  if constexpr (G >= 32) { uint32_t a, b; swap16_pair((uint32_t)v, a, b); v = (int)(a + b); }
+  return v;
+}
+// bit i = predicate of lane i of the caller's group
+template <int G>
+__device__ __forceinline__ uint64_t group_ballot(bool pred) {
+  const uint64_t m = __ballot(pred);
+  if constexpr (G == 64) return m;
+  return (m >> (threadIdx.x & 63u & ~(unsigned)(G - 1))) & ((1ull << G) - 1ull);
+}
+// value of lane `src` of the caller's group (src identical in the group's lanes) in every lane of the group
+template <int G>
+__device__ __forceinline__ int group_bcast(int v, int src) {
+  if constexpr (G == 64) return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+  return __builtin_amdgcn_ds_bpermute((int)(((threadIdx.x & 63u & ~(unsigned)(G - 1)) + (unsigned)src) << 2), v);
+}
+template <int G>
+__device__ __forceinline__ double group_bcast(double v, int src) {
+  const uint64_t x = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)group_bcast<G>((int)(uint32_t)x, src);
+  const uint32_t hi = (uint32_t)group_bcast<G>((int)(uint32_t)(x >> 32), src);
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// value of lane `src` of the caller's group, src chosen per lane (ds_bpermute_b32: the LDS crossbar, no LDS memory).  Every lane of the
+// group must call it (a lane that is switched off hands out 0).
+template <int G>
+__device__ __forceinline__ double group_gather(double v, int src) {
+  const int addr = (int)(((threadIdx.x & 63u & ~(unsigned)(G - 1)) + (unsigned)src) << 2);
+  const uint64_t x = (uint64_t)__double_as_longlong(v);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)x);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(x >> 32));
+  return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// LDS hand-off inside one wavefront (one lane of a group writes, the group's other lanes read): DS operations of a wavefront execute in
+// order, so all that is needed is that the compiler keeps the order (and waits for outstanding returns).  Unlike __syncthreads() this
+// may be called by groups in different branches.
+template <int G>
+__device__ __forceinline__ void group_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+
 // ---- lane-layout memory access through a buffer resource (SRSRC) ---------------------------
 // address = base (descriptor, 4 SGPRs) + soff (SGPR: row * ld * sizeof(R), wave-uniform) + voff
 // (ONE VGPR: lane * sizeof(R)) -> `buffer_load_dword v, v_off, s[rsrc], s_row offen`.  No 64-bit

@@ -1,4 +1,4 @@
-// solve_kernel.hip -- batched SE(3) MPC solve: one 64-lane wavefront per problem.
+// solve_kernel.hip -- batched SE(3) MPC solve: G lanes per problem (G = 8, 16, 32 or 64), 64 / G problems per wavefront.
 //
 // Replaces SE3MPCPlanner._solve_se3_mpc (reference planner.py:230-280): cold start (:329-359),
 // box (:378-402), scipy.optimize.minimize(method="L-BFGS-B", jac=_objective_gradient, bounds,
@@ -7,16 +7,20 @@
 // implementation of the published algorithm (Byrd-Lu-Nocedal-Zhu 1995; Morales-Nocedal 2011;
 // More-Thuente line search), structured like oracle/lbfgsb_port.py which is pinned to SciPy.
 //
-// Mapping.  n = 9N <= 576 decision variables; lane L owns J = 3*ceil(3N/64) register slots, slot j =
-// element L + 64 (j mod JB) of block j / JB (positions, velocities, thrusts: "slot layout" below;
-// J is a template parameter, so x, g, d, z, x_old, g_old live in registers and every slot's objective
-// term and box are fixed at compile time).  Dot
-// products / norms / argmins are per-lane partials + a DPP wavefront reduction (no LDS).  The
-// L-BFGS pairs S, Y (m x n) live in LDS, each lane touching only its own elements (bank = lane:
-// conflict free).  The m x m / 2m x 2m middle matrices and their Cholesky / triangular solves
-// are "scalar sections": lane 0 runs them on LDS, the wavefront re-converges at a barrier and
-// reads the results as LDS broadcasts.  Every quantity that feeds a branch of the algorithm is
-// computed in double; the _f32 entry point only stores S, Y and the results in float.
+// Mapping.  n = 9N decision variables, N <= 64.  Lane k of a problem's group owns horizon step k: its nine register
+// slots are (block, axis) = P_k, V_k, T_k -- block, axis, objective term and box of every slot are compile-time facts,
+// the only per-lane facts are "k >= N" (padding lane: variables fixed at 0) and "k == N - 1" (terminal position row).
+// The group size G is the smallest of 8 / 16 / 32 / 64 that holds the horizon (the host widens it while that still
+// fills the chip), so the reference's default horizon 6 packs eight problems into one wavefront, horizon 30 two.
+// Everything that was wave-uniform in a one-problem-per-wavefront kernel (the L-BFGS scalars, the line-search
+// state, the 2col x 2col middle matrices) is group-uniform here: groups of a wavefront are independent problems in
+// (possibly) different branches.  Dot products / norms / argmins are per-lane partials + a group-local all-reduce
+// (in-row DPP butterfly, + v_permlane16_swap for G = 32; G = 64: the whole-wavefront DPP reduction whose result
+// is an SGPR).  The L-BFGS pairs S, Y live in LDS, each lane touching only its own elements (bank = lane:
+// conflict free).  The m x m / 2m x 2m middle matrices and their Cholesky / triangular solves run in registers
+// of every lane for col <= 2 (all a solve with the reference's options ever needs) and as "scalar sections" of the
+// group's first lane on LDS beyond.  Every quantity that feeds a branch of the algorithm is computed in double; the
+// _f32 entry point only stores S, Y and the results in float.
 // No global memory is touched between reading (p0, v0, goal[, x0]) and writing the results.
 #include <hip/hip_runtime.h>
 
@@ -36,7 +40,7 @@
 #endif
 
 #ifndef SE3MPC_SOLVE_WAVES
-#define SE3MPC_SOLVE_WAVES 2      // resident wavefronts per SIMD the register allocation leaves room for (J <= 6); 3 was measured slower (spills)
+#define SE3MPC_SOLVE_WAVES 2      // resident wavefronts per SIMD the register allocation leaves room for
 #endif
 
 namespace se3mpc {
@@ -64,26 +68,6 @@ static SolveDev make_solve_dev(const se3mpc_params& p) {
   d.tz_lo = p.min_thrust; d.tz_hi = p.max_thrust;
   d.pgtol = p.pgtol; d.ftol = p.ftol;
   return d;
-}
-
-// Slot layout.  A lane keeps J = 3*JB elements in registers, JB = ceil(3N / 64) slots per block of the decision vector: slot j holds element
-// r = lane + 64*(j % JB) of block j / JB (0 positions, 1 velocities, 2 thrusts), i.e. decision-vector element (j / JB)*3N + r.  Every slot is
-// block-uniform, so which objective term and which box a slot needs is known when the J-loops are unrolled; only the axis (r % 3), the terminal
-// position row and the padding (r >= 3N, possible in the last slot of a block only) differ between lanes.
-// per-element code: bits 0-1 block (0 P, 1 V, 2 T, 3 padding), bits 2-3 axis, bit 4 terminal P row
-__device__ __forceinline__ int slot_code(const SolveDev& q, int blk, int r) {
-  if (r >= 3 * q.N) return 3;
-  const int k = r / 3, a = r - 3 * k;
-  return blk | (a << 2) | ((blk == 0 && k == q.N - 1) ? 16 : 0);
-}
-template <int J>
-__device__ __forceinline__ void slot_bounds(const SolveDev& q, int j, int code, double& lo, double& hi) {
-  constexpr int JB = J / 3;
-  const int blk = j / JB;
-  if (blk == 0) { lo = -q.pos_b; hi = q.pos_b; }
-  else if (blk == 1) { lo = -q.v_max; hi = q.v_max; }
-  else { const bool zax = ((code >> 2) & 3) == 2; lo = zax ? q.tz_lo : -q.txy; hi = zax ? q.tz_hi : q.txy; }
-  if (j % JB == JB - 1 && (code & 3) == 3) { lo = 0.0; hi = 0.0; }
 }
 
 // Moré-Thuente safeguarded step (MINPACK-2 dcstep).
@@ -420,30 +404,61 @@ __device__ __forceinline__ int formk_factor_regs(double (&wn)[2 * C][2 * C]) {
   return 0;
 }
 
+
 template <int C>
 struct ColTag { static constexpr int value = C; };
 
+// Compiler-only memory barrier (no instruction).  The S, Y pairs are read from LDS in four phases of the subspace step; without this the
+// compiler merges the four reads of every element and keeps all 2 * col * 9 values in registers across the whole section (36 VGPRs in the
+// float kernel, 72 in the double one), which is what pushed the packed kernels over 256 registers.  LDS reads are cheap; spills are not.
+__device__ __forceinline__ void reload_lds() { asm volatile("" ::: "memory"); }
+
+// Identity the compiler cannot see through (no instruction).  The line search saves x_old = x; everything it could recompute from x_old
+// (the step z - x_old, the old gradient) the compiler would otherwise recognise as values it already holds and KEEP them in registers
+// across the search -- 36 VGPRs at the kernel's pressure peak.  With x_old opaque those values are dead during the search and are
+// formed again (same expressions, same bits) where they are used.
+__device__ __forceinline__ double opaque(double v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(v));
+#endif
+  return v;
+}
+
 // ---- the solver ------------------------------------------------------------------------------
+constexpr int kSlots = 9;            // register slots of a lane: slot j = (block j / 3, axis j % 3) of the lane's horizon step
+
+// box of slot j (planner.py:378-402); j is a compile-time constant wherever this is called from an unrolled loop
+__device__ __forceinline__ double box_lo(const SolveDev& q, int j) { return j < 3 ? -q.pos_b : (j < 6 ? -q.v_max : (j < 8 ? -q.txy : q.tz_lo)); }
+__device__ __forceinline__ double box_hi(const SolveDev& q, int j) { return j < 3 ? q.pos_b : (j < 6 ? q.v_max : (j < 8 ? q.txy : q.tz_hi)); }
+
+// doubles of LDS per problem for the small matrices with storage for m pairs: sy, ss, wt [m][m], wn [2m][2m], pv, cv, vv, wbp, wv [2m],
+// sc [8]; made odd so that the broadcast reads of the (up to eight) problems of a wavefront fall into different banks
+__host__ __device__ constexpr int small_doubles(int m) { return (7 * m * m + 10 * m + 8) | 1; }
+
 // 2nd launch-bounds argument = wavefronts per SIMD the register allocation must leave room for: two
-// resident solves per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
-template <typename IO, int J>
-__global__ void __launch_bounds__(64, (J <= 6 ? SE3MPC_SOLVE_WAVES : 1))
+// resident wavefronts per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
+template <typename IO, int G>
+__global__ void __launch_bounds__(64, SE3MPC_SOLVE_WAVES)
 solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict__ v0g, const IO* __restrict__ goalg,
              const IO* __restrict__ x0g, IO* __restrict__ Xg, se3mpc_solve_info* __restrict__ infog,
              IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg) {
   HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  constexpr int P = kWave / G, J = kSlots;
   const int lane = lane_id();
-  const int pb = blockIdx.x;               // problem index
-  const int n = q.n, N = q.N, npad = kWave * J;
-  // Two-tier memory: the first launch gives every problem LDS for `mlds` (<= 4) L-BFGS pairs, which is all a
-  // solve with the reference's options ever stores (it stops after 1-3 iterations) and doubles the
-  // wavefronts a CU can hold; a problem that needs a pair more leaves with task = SE3MPC_TASK_OVERFLOW and
-  // is re-solved from scratch by the second launch (mlds = maxcor, only_overflow = 1), in which every other
-  // wavefront exits at once.  `m` below is the STORAGE bound; the algorithm's memory is still q.m.
+  const int k = lane & (G - 1);            // horizon step owned by this lane
+  const int grp = lane / G;                // problem slot inside the wavefront
+  const int pb = blockIdx.x * P + grp;     // problem index
+  if (pb >= B) return;                     // (a whole group leaves together)
+  const int n = q.n, N = q.N, n3 = 3 * q.N;
+  // Two-tier memory: the first launch gives every problem LDS for `mlds` L-BFGS pairs (2-4: all a solve with the reference's options
+  // ever stores -- it stops after 1-3 iterations, i.e. at most two updates) so that two wavefronts per SIMD fit a CU's LDS; a
+  // problem that needs a pair more leaves with task = SE3MPC_TASK_OVERFLOW and is re-solved from scratch by the second launch
+  // (mlds = maxcor, only_overflow = 1), in which every other group exits at once.  `m` below is the STORAGE bound; the
+  // algorithm's memory is still q.m.
   if (q.only_overflow && infog[pb].task != SE3MPC_TASK_OVERFLOW) return;
   const int m = q.mlds;
-  // LDS carve-up: doubles first, then the S / Y pairs in the IO type
-  double* sy = reinterpret_cast<double*>(lds_raw);     // [m][m]  S'Y (lower triangle used)
+  // LDS carve-up: per-problem small matrices (doubles) first, then the S / Y pairs of the whole wavefront in the IO type
+  double* sy = reinterpret_cast<double*>(lds_raw) + grp * small_doubles(m);   // [m][m]  S'Y (lower triangle used)
   double* ss = sy + m * m;                             // [m][m]  S'S (upper triangle used)
   double* wt = ss + m * m;                             // [m][m]  Cholesky factor of theta*S'S + L D^-1 L'
   double* wn = wt + m * m;                             // [2m][2m] LEL' factor of the subspace K matrix
@@ -453,23 +468,27 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   double* wbp = vv + 2 * m;                            // [2m]  row of W at a breakpoint
   double* wv = wbp + 2 * m;                            // [2m]  subspace rhs
   double* sc = wv + 2 * m;                             // [8]   scalars handed out of scalar sections
-  double* xlast = sc + 8;                              // [npad] the x of the last counted evaluation
-  IO* ws = reinterpret_cast<IO*>(xlast + npad);        // [m][npad]
-  IO* wy = ws + m * npad;                              // [m][npad]
-  double* scratch = reinterpret_cast<double*>(ws);     // reused after the solve (needs 12*64 doubles <= 2*m*npad*sizeof(IO))
+  IO* ws = reinterpret_cast<IO*>(reinterpret_cast<double*>(lds_raw) + P * small_doubles(m));   // [m][9][64]
+  IO* wy = ws + m * J * kWave;                         // [m][9][64]
 
-  // ---- per-element constants and problem data
-  int code[J];
-  double x[J], g[J], z[J], d[J], xo[J], go[J];
-  const double goal0 = q.has_goal ? (double)goalg[pb * 3 + 0] : 0.0;
-  const double goal1 = q.has_goal ? (double)goalg[pb * 3 + 1] : 0.0;
-  const double goal2 = q.has_goal ? (double)goalg[pb * 3 + 2] : 0.0;
-  auto goal_of = [&](int cd) { const int a = (cd >> 2) & 3; return a == 0 ? goal0 : (a == 1 ? goal1 : goal2); };
-  // the state too is fetched here, at wave-uniform addresses, next to the goal: nine independent loads in flight at once.  (Inside the
-  // per-element branches below each element's load was issued only when its branch was reached: J dependent HBM round trips.)
+  // ---- per-lane facts and problem data
+  const bool live = k < N;                 // k >= N: padding lane, its nine variables are fixed at 0
+  const bool last = k == N - 1;            // terminal position row
+  double goal[3] = {0.0, 0.0, 0.0};
+  if (q.has_goal) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) goal[a] = (double)goalg[pb * 3 + a];
+  }
   const bool cold = x0g == nullptr;
-  const double ps0 = cold ? (double)p0g[pb * 3 + 0] : 0.0, ps1 = cold ? (double)p0g[pb * 3 + 1] : 0.0, ps2 = cold ? (double)p0g[pb * 3 + 2] : 0.0;
-  const double vs0 = cold ? (double)v0g[pb * 3 + 0] : 0.0, vs1 = cold ? (double)v0g[pb * 3 + 1] : 0.0, vs2 = cold ? (double)v0g[pb * 3 + 2] : 0.0;
+  double ps[3] = {0.0, 0.0, 0.0}, vs[3] = {0.0, 0.0, 0.0};
+  if (cold) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { ps[a] = (double)p0g[pb * 3 + a]; vs[a] = (double)v0g[pb * 3 + a]; }
+  }
+  // the goal coordinate the objective sees: 0 on a padding lane, whose position slots then have gradient 0 like its other slots
+  double gl[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) gl[a] = live ? goal[a] : 0.0;
 
 #ifdef SE3MPC_SOLVE_PROFILE
   __shared__ unsigned long long tsec[16];                     // in LDS (lane 0 adds): eight SGPR pairs of counters would change the register allocation measured
@@ -479,130 +498,109 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   const unsigned long long tstart = tlast;
 #endif
   // ---- cold start (planner.py:329-359) or caller x0, projected into the box (L-BFGS-B `active`)
-  constexpr int JB = J / 3;
-  const int n3 = 3 * N;
-  double xw[J];
+  double x[J], g[J], z[J], d[J], xo[J];
 #pragma unroll
   for (int j = 0; j < J; ++j) {
-    const int r = lane + kWave * (j % JB);
-    xw[j] = (!cold && r < n3) ? (double)x0g[(size_t)pb * n + (j / JB) * n3 + r] : 0.0;
-  }
-#pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int blk = j / JB, r = lane + kWave * (j % JB);
-    code[j] = slot_code(q, blk, r);
-    double lo, hi;
-    slot_bounds<J>(q, j, code[j], lo, hi);
+    const int blk = j / 3, a = j % 3;
     double xv = 0.0;
-    const int a = (code[j] >> 2) & 3;
-    if ((code[j] & 3) != 3) {
-      if (!cold) {
-        xv = xw[j];
-      } else {
-        const int k = r / 3;
-        const double pa = a == 0 ? ps0 : (a == 1 ? ps1 : ps2), va = a == 0 ? vs0 : (a == 1 ? vs1 : vs2), ga = goal_of(code[j]);
-        const double denom = (double)(N - 1 > 1 ? N - 1 : 1);
-        if (blk == 0) {
-          const double alpha = (double)k / denom;
-          xv = q.has_goal ? (1.0 - alpha) * pa + alpha * ga : pa;
-        } else if (blk == 1) {
-          if (k == 0) xv = va;
-          else if (q.has_goal) {
-            const double a1 = (double)k / denom, a0 = (double)(k - 1) / denom;
-            xv = (((1.0 - a1) * pa + a1 * ga) - ((1.0 - a0) * pa + a0 * ga)) / q.dt;
-          } else xv = 0.0;
-        } else {
-          xv = (a == 2) ? q.hover : 0.0;
+    if (!cold) {
+      xv = live ? (double)x0g[(size_t)pb * n + blk * n3 + 3 * k + a] : 0.0;
+    } else {
+      const double denom = (double)(N - 1 > 1 ? N - 1 : 1);
+      if (blk == 0) {
+        const double alpha = (double)k / denom;
+        xv = q.has_goal ? (1.0 - alpha) * ps[a] + alpha * goal[a] : ps[a];
+      } else if (blk == 1) {
+        if (q.has_goal) {
+          const double a1 = (double)k / denom, a0 = (double)(k - 1) / denom;
+          xv = (((1.0 - a1) * ps[a] + a1 * goal[a]) - ((1.0 - a0) * ps[a] + a0 * goal[a])) / q.dt;
         }
+        xv = (k == 0) ? vs[a] : xv;
+      } else {
+        xv = (a == 2) ? q.hover : 0.0;
       }
     }
-    x[j] = fmin(fmax(xv, lo), hi);
-    g[j] = 0.0; z[j] = x[j]; d[j] = 0.0; xo[j] = x[j]; go[j] = 0.0;
+    x[j] = live ? fmin(fmax(xv, box_lo(q, j)), box_hi(q, j)) : 0.0;
+    g[j] = 0.0; z[j] = x[j]; d[j] = 0.0; xo[j] = x[j];
   }
-  // the goal coordinate of every position slot's element, selected once (the objective asks for it at every evaluation)
-  double gsel[JB];
-#pragma unroll
-  for (int j = 0; j < JB; ++j) gsel[j] = goal_of(code[j]);
 
-  // objective (planner.py:516-550) and the reference's gradient (planner.py:552-580) at x
-  // nfev counts like scipy's ScalarFunction: asking again for the x evaluated last (a line search
-  // whose steps shrank below rounding) returns the same (f, g) and is not counted.
-  int nfev = 0;
-  // with_gd: also return g(x)'d, its reduction interleaved with the objective's (the line search wants both)
+  // the reference's gradient (planner.py:552-580) of one slot.  The same expression wherever a gradient value is needed again (the
+  // previous iterate's gradient in the BFGS update and after a failed line search is RECOMPUTED from the saved x, not kept in nine more
+  // register pairs); contraction off so that both places round the product the same way.
+  auto grad_of = [&](int j, double xv) -> double {
+#pragma clang fp contract(off)
+    if (j < 3) return q.has_goal ? 2.0 * q.wp * (xv - gl[j]) : 0.0;
+    if (j < 6) return 2.0 * q.wv * xv;
+    return 2.0 * q.wT * xv;
+  };
+  // objective (planner.py:516-550) and gradient at x; with_gd: also g(x)'d, its reduction interleaved with the objective's (the
+  // line search wants both)
+  // A line-search evaluation (with_gd) does not store the gradient: it only needs g(x)'d, and the nine gradient values are formed again
+  // from x when the search has ended -- so that no gradient registers are live across the line search, the kernel's pressure peak.
   double gd_fused = 0.0;
   auto eval_fg = [&](bool with_gd = false) -> double {
-    bool moved = false;
+    double part = 0.0, gdp = 0.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) moved = moved | !(x[j] == xlast[lane + kWave * j]);   // | not ||: per-lane flags accumulate without divergent branches
-    if (wave_ballot(moved) != 0ull) {
-      ++nfev;
-#pragma unroll
-      for (int j = 0; j < J; ++j) xlast[lane + kWave * j] = x[j];
-    }
-    double part = 0.0;
-#pragma unroll
-    for (int j = 0; j < J; ++j) {
-      const int blk = j / JB, a = (code[j] >> 2) & 3;
-      const bool pad = (j % JB == JB - 1) && (code[j] & 3) == 3;      // padding lanes hold x = 0: the V terms vanish by themselves
-      const double xv = x[j];
-      double fj = 0.0, gj = 0.0;
-      if (blk == 0) {
-        if (q.has_goal) {
-          const double e = xv - gsel[j % JB];
-          fj = q.wp * (e * e);
-          if (code[j] & 16) fj += q.term * q.wp * (e * e);
-          gj = 2.0 * q.wp * e;
-          if (pad) { fj = 0.0; gj = 0.0; }
-        }
-      } else if (blk == 1) {
-        fj = q.wv * (xv * xv); gj = 2.0 * q.wv * xv;
-      } else {
-        const double ac = xv / q.mass - (a == 2 ? q.grav : 0.0);
-        const double dv = xv - (a == 2 ? q.hover : 0.0);
-        fj = q.wa * (ac * ac) + q.wT * (dv * dv);
-        gj = 2.0 * q.wT * xv;
-        if (pad) fj = 0.0;
+    for (int a = 0; a < 3; ++a) {
+      if (q.has_goal) {
+        const double e = x[a] - gl[a];
+        double fj = q.wp * (e * e);
+        const double ft = q.term * q.wp * (e * e);
+        fj = last ? fj + ft : fj;
+        part += fj;
       }
-      part += fj;
-      g[j] = gj;
     }
-    if (with_gd) {
-      double gdp = 0.0;
 #pragma unroll
-      for (int j = 0; j < J; ++j) gdp += g[j] * d[j];
+    for (int a = 0; a < 3; ++a) {
+      const double xv = x[3 + a];
+      part += q.wv * (xv * xv);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const double xv = x[6 + a];
+      const double ac = xv / q.mass - (a == 2 ? q.grav : 0.0);
+      const double dv = xv - (a == 2 ? q.hover : 0.0);
+      part += q.wa * (ac * ac) + q.wT * (dv * dv);
+    }
+    part = live ? part : 0.0;
+    if (with_gd) {
+#pragma unroll
+      for (int j = 0; j < J; ++j) gdp += grad_of(j, x[j]) * (z[j] - xo[j]);      // d = z - x_old, formed here (see opaque())
       double r2[2] = {part, gdp};
-      wave_sum_n<2>(r2);
+      group_sum_n<G, 2>(r2);
       gd_fused = r2[1];
       return r2[0];
     }
-    return wave_sum(part);
+#pragma unroll
+    for (int j = 0; j < J; ++j) g[j] = grad_of(j, x[j]);
+    return group_sum<G>(part);
   };
   // projected gradient norm (projgr)
   auto projgr = [&]() -> double {
     double mx = 0.0;
 #pragma unroll
     for (int j = 0; j < J; ++j) {
-      double lo, hi;
-      slot_bounds<J>(q, j, code[j], lo, hi);
       const double gj = g[j];
-      const double up = fmax(x[j] - hi, gj), dn = fmin(x[j] - lo, gj);      // both sides, then one select: no divergent branches
-      double gi = gj < 0.0 ? up : dn;
-      if (j % JB == JB - 1 && (code[j] & 3) == 3) gi = 0.0;
+      const double up = fmax(x[j] - box_hi(q, j), gj), dn = fmin(x[j] - box_lo(q, j), gj);      // both sides, then one select: no divergent branches
+      const double gi = gj < 0.0 ? up : dn;
       mx = fmax(mx, fabs(gi));
     }
-    return wave_max(mx);
+    mx = live ? mx : 0.0;
+    return group_max<G>(mx);
   };
-  auto WS = [&](int c, int j) -> IO& { return ws[c * npad + lane + kWave * j]; };
-  auto WY = [&](int c, int j) -> IO& { return wy[c * npad + lane + kWave * j]; };
+  auto WS = [&](int c, int j) -> IO& { return ws[(c * J + j) * kWave + lane]; };
+  auto WY = [&](int c, int j) -> IO& { return wy[(c * J + j) * kWave + lane]; };
 
-  // ---- L-BFGS-B state (identical in every lane)
+  // ---- L-BFGS-B state (identical in every lane of the group)
   int col = 0, iupdat = 0, iter = 0, nit = 0;
   double theta = 1.0;
   int iwhere[J];
 #pragma unroll
-  for (int j = 0; j < J; ++j) iwhere[j] = ((code[j] & 3) == 3) ? 3 : 0;   // padding = fixed variables
-#pragma unroll
-  for (int j = 0; j < J; ++j) xlast[lane + kWave * j] = __builtin_nan("");
+  for (int j = 0; j < J; ++j) iwhere[j] = live ? 0 : 3;   // padding = fixed variables
+  // nfev counts like scipy's ScalarFunction: asking again for the x evaluated last (a line search whose steps shrank below
+  // rounding) returns the same (f, g) and is not counted.  x_is_last: the registers x hold the x of the last evaluation.
+  int nfev = 1;
+  bool x_is_last = true;
   double f = eval_fg();
   double sbgnrm = projgr();
   int status = 0, task = 0;
@@ -624,14 +622,13 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
       for (int j = 0; j < J; ++j) {
         // written as value selects throughout: as nested ifs this loop became ~50 exec-mask instructions per slot
-        double lo, hi;
-        slot_bounds<J>(q, j, code[j], lo, hi);
+        const double lo = box_lo(q, j), hi = box_hi(q, j);
         const double neggi = -g[j];
         const double tl = x[j] - lo, tu = hi - x[j];
         const bool xlower = tl <= 0.0, xupper = tu <= 0.0;
         const int atlo = neggi <= 0.0 ? 1 : 0, athi = neggi >= 0.0 ? 2 : 0, flat = fabs(neggi) <= 0.0 ? -3 : 0;
         const int iwb = xlower ? atlo : (xupper ? athi : flat);
-        const int iw = iwhere[j] != 3 ? iwb : 3;
+        const int iw = live ? iwb : 3;                       // (nothing of the previous iterate's iwhere survives but "padding lane" = fixed)
         iwhere[j] = iw;
         const bool moving = iw == 0;
         const double dj = moving ? neggi : 0.0;
@@ -645,7 +642,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         nbr += brk ? 1 : 0;
         z[j] = x[j];
       }
-      // tbp[] holds numerators until this turns them into breakpoints (six f64 divisions per lane)
+      // tbp[] holds numerators until this turns them into breakpoints (nine f64 divisions per lane)
       auto breakpoints = [&]() {
 #pragma unroll
         for (int j = 0; j < J; ++j) tbp[j] = tbp[j] / fabs(g[j]);            // +inf / |g| stays +inf (|g| is finite); brk implies g != 0
@@ -658,39 +655,37 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         // search of the published algorithm (f1_k = -(D - S_k)(1 - theta*t_k), f2_k = theta*(D - S_k), hence
         // dtm_k = 1/theta - t_k at every breakpoint) crosses exactly the breakpoints t_i <= 1/theta and stops
         // at t = 1/theta.  This is where ~170 of a typical solve's ~172 crossings happen (all of them at
-        // the first iterate), so they are taken in one parallel pass instead of 170 wavefront reductions.
+        // the first iterate), so they are taken in one parallel pass instead of 170 group reductions.
         if (sbgnrm > 0.0) {
           const double tstar = 1.0 / theta;
           const bool unit = theta == 1.0;                                  // the first iterate of every solve
           if (!unit) breakpoints();
 #pragma unroll
           for (int j = 0; j < J; ++j) {
-            double lo, hi;
-            slot_bounds<J>(q, j, code[j], lo, hi);
             // fl(num / |g|) <= 1 <=> num <= |g| (rounding is monotone and fl(1) = 1): no quotient while theta is 1
             const bool reached = unit ? tbp[j] <= fabs(g[j]) : tbp[j] <= tstar;
-            const bool hit = iwhere[j] == 0 && reached;                    // d is 0 wherever iwhere != 0: z + tstar*d leaves those alone
+            const bool hit = (iwhere[j] == 0) & reached;                   // d is 0 wherever iwhere != 0: z + tstar*d leaves those alone
             const bool upw = d[j] > 0.0;
-            z[j] = hit ? (upw ? hi : lo) : z[j] + tstar * d[j];
+            z[j] = hit ? (upw ? box_hi(q, j) : box_lo(q, j)) : z[j] + tstar * d[j];
             iwhere[j] = hit ? (upw ? 2 : 1) : iwhere[j];
             d[j] = hit ? 0.0 : d[j];
           }
         }
         SE3MPC_TICK(9)
       } else {
-      double f1 = wave_sum(f1p);
-      const int nbreak = wave_sum_i32(nbr);
-      // p = W'd (2col wavefront reductions), second half scaled by theta
+      double f1 = group_sum<G>(f1p);
+      const int nbreak = group_sum_i32<G>(nbr);
+      // p = W'd (2col group reductions), second half scaled by theta
       for (int c = 0; c < col; ++c) {
         double a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
         double r2[2] = {a1, a2};
-        wave_sum_n<2>(r2);
+        group_sum_n<G, 2>(r2);
         a1 = r2[0]; a2 = r2[1];
-        if (lane == 0) { pv[c] = a1; pv[col + c] = theta * a2; cv[c] = 0.0; cv[col + c] = 0.0; }
+        if (k == 0) { pv[c] = a1; pv[col + c] = theta * a2; cv[c] = 0.0; cv[col + c] = 0.0; }
       }
-      __syncthreads();
+      group_sync<G>();
       if (sbgnrm > 0.0 && nbreak > 0) {
         double f2 = -theta * f1;
         const double f2_org = f2;
@@ -710,16 +705,16 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           };
           if (col == 1) init_fast(ColTag<1>{}); else init_fast(ColTag<2>{});
         } else if (col > 0) {
-          if (lane == 0) {
+          if (k == 0) {
             const int inf = bmv(sy, wt, m, col, pv, vv);
             double dot = 0.0;
             for (int i = 0; i < 2 * col; ++i) dot += vv[i] * pv[i];
             sc[0] = dot; sc[1] = (double)inf;
           }
-          __syncthreads();
+          group_sync<G>();
           info = (int)sc[1];
           f2 -= sc[0];
-          __syncthreads();
+          group_sync<G>();
         }
         SE3MPC_TICK(10)
         if (info == 0) {
@@ -727,26 +722,25 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           int nleft = nbreak;
           bool all_fixed = false;
           // The search below stops before its first crossing when dtm < min_j t_j.  num * (1 - 2^-50) > dtm * |g| (both products rounded) implies
-          // num / |g| > dtm * (1 + 2^-51), hence fl(num / |g|) > dtm: if that holds in every lane the loop would do nothing but form the six
-          // quotients per lane and their wavefront minimum -- skipped.  Otherwise (a crossing, or too close to call) the published search runs.
-          // (accumulated with `&`: as a short-circuit `&&` chain this became nine nested divergent regions, and the J = 9 float32 kernel, whose
-          // register spills to AGPRs landed inside them, then returned a wrong Cauchy point on the GPU -- found by the golden solves, N = 50)
+          // num / |g| > dtm * (1 + 2^-51), hence fl(num / |g|) > dtm: if that holds in every lane the loop would do nothing but form the nine
+          // quotients per lane and their group minimum -- skipped.  Otherwise (a crossing, or too close to call) the published search runs.
+          // (accumulated with `&`, not a short-circuit `&&` chain: straight-line compares instead of nine nested divergent regions)
           bool clear = dtm > 0.0;
 #pragma unroll
-          for (int j = 0; j < J; ++j) clear = clear & (tbp[j] * 0.99999999999999911182158029987 > dtm * fabs(g[j]));   // & not &&: straight-line compares
-          const bool skip_search = wave_ballot(!clear) == 0ull;
+          for (int j = 0; j < J; ++j) clear = clear & (tbp[j] * 0.99999999999999911182158029987 > dtm * fabs(g[j]));
+          const bool skip_search = group_ballot<G>(!clear) == 0ull;
           if (!skip_search) breakpoints();
           while (!skip_search && nleft > 0) {
-            // next smallest breakpoint: per-lane min, DPP min, owner = first lane holding it
+            // next smallest breakpoint: per-lane min, group min, owner = first lane holding it
             double tmin = tbp[0];
             int jm = 0;
 #pragma unroll
             for (int j = 1; j < J; ++j) if (tbp[j] < tmin) { tmin = tbp[j]; jm = j; }
             const double tj0 = tj;
-            tj = wave_min(tmin);
-            const int src = first_lane(wave_ballot(tmin == tj));
+            tj = group_min<G>(tmin);
+            const int src = first_lane(group_ballot<G>(tmin == tj));
             if (src < 0) { info = 1; break; }                 // NaN breakpoints: give up on this memory
-            const int jsel = wave_bcast(jm, src);
+            const int jsel = group_bcast<G>(jm, src);
             const double dt = tj - tj0;
             if (dtm < dt) break;
             tsum += dt;
@@ -756,65 +750,36 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             double dib = 0.0, zib = 0.0;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-              if (j == jsel && lane == src) {
-                double lo, hi;
-                slot_bounds<J>(q, j, code[j], lo, hi);
+              if (j == jsel && k == src) {
+                const double lo = box_lo(q, j), hi = box_hi(q, j);
                 dib = d[j]; d[j] = 0.0; tbp[j] = kInf;
                 if (dib > 0.0) { zib = hi - x[j]; z[j] = hi; iwhere[j] = 2; }
                 else { zib = lo - x[j]; z[j] = lo; iwhere[j] = 1; }
               }
             }
-            const double dibp = wave_bcast(dib, src), zibp = wave_bcast(zib, src);
+            const double dibp = group_bcast<G>(dib, src), zibp = group_bcast<G>(zib, src);
             if (nleft == 0 && nbreak == n) { dtm = dt; all_fixed = true; break; }
             const double dibp2 = dibp * dibp;
             f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
             f2 = f2 - theta * dibp2;
-            if (col > 0 && col <= kFastCol) {
-              const int ibp = src + kWave * jsel;
-              auto step_fast = [&](auto tag) {
-                constexpr int C = decltype(tag)::value;
-                MidRegs<C> M;
-                load_mid<C>(sy, wt, m, M);
-                double pr[2 * C], cr[2 * C], wb[2 * C], vr[2 * C];
-#pragma unroll
-                for (int i = 0; i < 2 * C; ++i) { pr[i] = pv[i]; cr[i] = cv[i]; }
-#pragma unroll
-                for (int c = 0; c < C; ++c) { wb[c] = (double)wy[c * npad + ibp]; wb[C + c] = theta * (double)ws[c * npad + ibp]; }
-#pragma unroll
-                for (int i = 0; i < 2 * C; ++i) cr[i] += dt * pr[i];
-                info = bmv_regs<C>(M, wb, vr);
-                double wmc = 0.0, wmp = 0.0, wmw = 0.0;
-#pragma unroll
-                for (int i = 0; i < 2 * C; ++i) { wmc += cr[i] * vr[i]; wmp += pr[i] * vr[i]; wmw += wb[i] * vr[i]; }
-#pragma unroll
-                for (int i = 0; i < 2 * C; ++i) pr[i] -= dibp * wb[i];
-                __syncthreads();                               // every lane has read pv / cv before lane 0 overwrites them
-                if (lane == 0) {
-#pragma unroll
-                  for (int i = 0; i < 2 * C; ++i) { pv[i] = pr[i]; cv[i] = cr[i]; }
-                }
-                __syncthreads();
-                f1 += dibp * wmc;
-                f2 += 2.0 * dibp * wmp - dibp2 * wmw;
-              };
-              if (col == 1) step_fast(ColTag<1>{}); else step_fast(ColTag<2>{});
-              if (info != 0) break;
-            } else if (col > 0) {
-              const int ibp = src + kWave * jsel;
-              if (lane == 0) {
+            const int ibp = jsel * kWave + (lane - k + src);       // the owner's element inside a pair's [9][64] image
+            // (the middle-matrix product of a crossing runs as a scalar section of the group's first lane for every col: a crossing with
+            // pairs in memory is rare -- none in a typical solve -- and its register form was one of the kernel's two pressure peaks)
+            if (col > 0) {
+              if (k == 0) {
                 for (int i = 0; i < 2 * col; ++i) cv[i] += dt * pv[i];
-                for (int c = 0; c < col; ++c) { wbp[c] = (double)wy[c * npad + ibp]; wbp[col + c] = theta * (double)ws[c * npad + ibp]; }
+                for (int c = 0; c < col; ++c) { wbp[c] = (double)wy[c * J * kWave + ibp]; wbp[col + c] = theta * (double)ws[c * J * kWave + ibp]; }
                 const int inf = bmv(sy, wt, m, col, wbp, vv);
                 double wmc = 0.0, wmp = 0.0, wmw = 0.0;
                 for (int i = 0; i < 2 * col; ++i) { wmc += cv[i] * vv[i]; wmp += pv[i] * vv[i]; wmw += wbp[i] * vv[i]; }
                 for (int i = 0; i < 2 * col; ++i) pv[i] -= dibp * wbp[i];
                 sc[0] = wmc; sc[1] = wmp; sc[2] = wmw; sc[3] = (double)inf;
               }
-              __syncthreads();
+              group_sync<G>();
               info = (int)sc[3];
               f1 += dibp * sc[0];
               f2 += 2.0 * dibp * sc[1] - dibp2 * sc[2];
-              __syncthreads();
+              group_sync<G>();
               if (info != 0) break;
             }
             f2 = fmax(kEps * f2_org, f2);
@@ -830,8 +795,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
               for (int j = 0; j < J; ++j) z[j] += tsum * d[j];
             }
             if (col > 0) {
-              if (lane == 0) for (int i = 0; i < 2 * col; ++i) cv[i] += dtm * pv[i];
-              __syncthreads();
+              if (k == 0) for (int i = 0; i < 2 * col; ++i) cv[i] += dtm * pv[i];
+              group_sync<G>();
             }
           }
         }
@@ -845,7 +810,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     int nfree_p = 0;
 #pragma unroll
     for (int j = 0; j < J; ++j) nfree_p += (iwhere[j] <= 0) ? 1 : 0;
-    const int nfree = wave_sum_i32(nfree_p);
+    const int nfree = group_sum_i32<G>(nfree_p);
     if (nfree != 0 && col != 0) {
       // wvr: the subspace solution (K^-1 W'Z r) of the fast path, in registers of every lane; the LDS path leaves it in wv[]
       double wvr[2 * kFastCol] = {0.0, 0.0, 0.0, 0.0};
@@ -857,26 +822,30 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
           for (int i = 0; i < 2 * C; ++i)
 #pragma unroll
-            for (int k = 0; k < 2 * C; ++k) wnr[i][k] = 0.0;
+            for (int kk = 0; kk < 2 * C; ++kk) wnr[i][kk] = 0.0;
           // all C*C cells' partial sums first, then ONE interleaved reduction of the 3 sums each cell needs (yzzy, saas for the
           // lower-left half, and the cross term: sa_y below the diagonal, sz_y on and above it)
           double sums[3 * C * C];
 #pragma unroll
-          for (int iy = 0; iy < C; ++iy) {
+          for (int i = 0; i < 3 * C * C; ++i) sums[i] = 0.0;
 #pragma unroll
-            for (int jy = 0; jy < C; ++jy) {
-              double yzzy = 0.0, saas = 0.0, sa_y = 0.0, sz_y = 0.0;
+          for (int j = 0; j < J; ++j) {                        // slot-outer: a slot's 2C values of S, Y are read once and folded into every cell
+            const bool fr = iwhere[j] <= 0;
+            double wyv[C], wsv[C];
 #pragma unroll
-              for (int j = 0; j < J; ++j) {
-                const bool fr = iwhere[j] <= 0;
-                const double wyi = (double)WY(iy, j), wyj = (double)WY(jy, j), wsi = (double)WS(iy, j), wsj = (double)WS(jy, j);
-                if (fr) { yzzy += wyi * wyj; sz_y += wsi * wyj; }
-                else { saas += wsi * wsj; sa_y += wsi * wyj; }
+            for (int c = 0; c < C; ++c) { wyv[c] = (double)WY(c, j); wsv[c] = (double)WS(c, j); }
+#pragma unroll
+            for (int iy = 0; iy < C; ++iy) {
+#pragma unroll
+              for (int jy = 0; jy < C; ++jy) {
+                const double yy = wyv[iy] * wyv[jy], sS = wsv[iy] * wsv[jy], sY = wsv[iy] * wyv[jy];
+                sums[3 * (iy * C + jy) + 0] += fr ? yy : 0.0;                                  // yzzy: free set
+                sums[3 * (iy * C + jy) + 1] += fr ? 0.0 : sS;                                  // saas: active set
+                sums[3 * (iy * C + jy) + 2] += ((jy < iy) ? !fr : fr) ? sY : 0.0;              // sa_y below the diagonal, sz_y on and above it
               }
-              sums[3 * (iy * C + jy) + 0] = yzzy; sums[3 * (iy * C + jy) + 1] = saas; sums[3 * (iy * C + jy) + 2] = (jy < iy) ? sa_y : sz_y;
             }
           }
-          wave_sum_n<3 * C * C>(sums);
+          group_sum_n<G, 3 * C * C>(sums);
 #pragma unroll
           for (int iy = 0; iy < C; ++iy) {
 #pragma unroll
@@ -889,6 +858,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
               wnr[jy][C + iy] = (jy < iy) ? -cross : cross;
             }
           }
+          reload_lds();
           int inf = formk_factor_regs<C>(wnr);
           SE3MPC_TICK(12)
           // ---- cmprlb, scalar part: mc = M c
@@ -908,6 +878,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             for (int c = 0; c < C; ++c) t += (double)WY(c, j) * mc[c] + (double)WS(c, j) * (theta * mc[C + c]);
             d[j] = (iwhere[j] <= 0) ? t : 0.0;
           }
+          reload_lds();
           // ---- subsm: wv = W'Z d ; wv = K^-1 wv   (d is 0 off the free set: no condition inside the sums)
           double wr[2 * C];
 #pragma unroll
@@ -917,9 +888,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
             wr[c] = a1; wr[C + c] = a2;
           }
-          wave_sum_n<2 * C>(wr);
+          group_sum_n<G, 2 * C>(wr);
 #pragma unroll
           for (int c = 0; c < C; ++c) wr[C + c] = theta * wr[C + c];
+          reload_lds();
           int inf2 = dtrsl_regs<2 * C>(wnr, wr, true);
           if (!inf2) {
 #pragma unroll
@@ -945,23 +917,23 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             }
             // wn (upper triangle, row stride 2m):  [ D + Y'ZZ'Y/theta   -L_a' + R_z' ;  .   theta S'AA'S ]
             if (jy <= iy) {
-              yzzy = wave_sum(yzzy); saas = wave_sum(saas);
-              if (lane == 0) {
+              yzzy = group_sum<G>(yzzy); saas = group_sum<G>(saas);
+              if (k == 0) {
                 wn[jy * 2 * m + iy] = yzzy / theta + (jy == iy ? sy[iy * m + iy] : 0.0);
                 wn[(col + jy) * 2 * m + (col + iy)] = saas * theta;
               }
             }
             if (jy < iy) {
-              sa_y = wave_sum(sa_y);
-              if (lane == 0) wn[jy * 2 * m + (col + iy)] = -sa_y;
+              sa_y = group_sum<G>(sa_y);
+              if (k == 0) wn[jy * 2 * m + (col + iy)] = -sa_y;
             } else {
-              sz_y = wave_sum(sz_y);
-              if (lane == 0) wn[jy * 2 * m + (col + iy)] = sz_y;
+              sz_y = group_sum<G>(sz_y);
+              if (k == 0) wn[jy * 2 * m + (col + iy)] = sz_y;
             }
           }
         }
-        __syncthreads();
-        if (lane == 0) {
+        group_sync<G>();
+        if (k == 0) {
           const int ld = 2 * m;
           int inf = dpofa(wn, ld, col);
           if (inf) inf = -1;
@@ -970,7 +942,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             for (int is = col; is < 2 * col; ++is)
               for (int js = is; js < 2 * col; ++js) {
                 double s = 0.0;
-                for (int k = 0; k < col; ++k) s += wn[k * ld + is] * wn[k * ld + js];
+                for (int kk = 0; kk < col; ++kk) s += wn[kk * ld + is] * wn[kk * ld + js];
                 wn[is * ld + js] += s;
               }
             if (dpofa(wn + col * ld + col, ld, col)) inf = -2;
@@ -979,7 +951,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           if (inf == 0 && bmv(sy, wt, m, col, cv, vv)) inf = -8;
           sc[0] = (double)inf;
         }
-        __syncthreads();
+        group_sync<G>();
         info = (int)sc[0];
         if (info == 0) {
           // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
@@ -996,12 +968,12 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   #pragma unroll
             for (int j = 0; j < J; ++j) if (iwhere[j] <= 0) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
             double r2[2] = {a1, a2};
-            wave_sum_n<2>(r2);
+            group_sum_n<G, 2>(r2);
             a1 = r2[0]; a2 = r2[1];
-            if (lane == 0) { wv[c] = a1; wv[col + c] = theta * a2; }
+            if (k == 0) { wv[c] = a1; wv[col + c] = theta * a2; }
           }
-          __syncthreads();
-          if (lane == 0) {
+          group_sync<G>();
+          if (k == 0) {
             int inf = dtrsl_upper(wn, 2 * m, 2 * col, wv, 1, true);
             if (!inf) {
               for (int i = 0; i < col; ++i) wv[i] = -wv[i];
@@ -1009,7 +981,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             }
             sc[0] = (double)inf;
           }
-          __syncthreads();
+          group_sync<G>();
           info = (int)sc[0];
         }
       }   // col > kFastCol: LDS path
@@ -1035,15 +1007,14 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             }
           }
           const double rth = 1.0 / theta;
-          // projected Newton point; xo/go are free here (the line search re-saves them): xo keeps xcp
+          // projected Newton point; xo is free here (the line search re-saves it): xo keeps xcp
           bool hitp = false;
           double ddp = 0.0;
 #pragma unroll
           for (int j = 0; j < J; ++j) {
             xo[j] = z[j];
             const bool fr = iwhere[j] <= 0;
-            double lo, hi;
-            slot_bounds<J>(q, j, code[j], lo, hi);
+            const double lo = box_lo(q, j), hi = box_hi(q, j);
             const double dn = d[j] * rth;
             const double xk = fmin(hi, fmax(lo, z[j] + dn));
             d[j] = fr ? dn : d[j];
@@ -1051,9 +1022,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             hitp = hitp | (fr & ((xk == lo) | (xk == hi)));
             ddp += (z[j] - x[j]) * g[j];
           }
-          const bool iword = wave_ballot(hitp) != 0ull;
+          const bool iword = group_ballot<G>(hitp) != 0ull;
           if (iword) {
-            const double dd_p = wave_sum(ddp);
+            const double dd_p = group_sum<G>(ddp);
             if (dd_p > 0.0) {
               // not a descent direction: back to xcp and truncate the Newton step at the first bound
               double amin = 1.0;
@@ -1062,25 +1033,26 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
               for (int j = 0; j < J; ++j) {
                 z[j] = xo[j];
                 if (iwhere[j] <= 0) {
-                  double lo, hi;
-                  slot_bounds<J>(q, j, code[j], lo, hi);
+                  const double lo = box_lo(q, j), hi = box_hi(q, j);
                   const double dk = d[j];
                   double cand = 1.0;
                   if (dk < 0.0) { const double t2 = lo - z[j]; cand = (t2 >= 0.0) ? 0.0 : ((dk * 1.0 < t2) ? t2 / dk : 1.0); }
                   else if (dk > 0.0) { const double t2 = hi - z[j]; cand = (t2 <= 0.0) ? 0.0 : ((dk * 1.0 > t2) ? t2 / dk : 1.0); }
-                  if (cand < amin) { amin = cand; imin = (unsigned)(lane + kWave * j); }
+                  // ties go to the variable that comes first in the reference's packing [P | V | T], row = 3k + axis (subsm's strict `<` in variable order):
+                  // inside a lane the slots are visited in that order, across lanes the smallest index wins below
+                  const unsigned idx = (unsigned)((j / 3) * n3 + 3 * k + (j % 3));
+                  if (cand < amin) { amin = cand; imin = idx; }
                 }
               }
-              const double alpha = wave_min(amin);
-              const unsigned ibd = wave_min_u32(amin == alpha && alpha < 1.0 ? imin : 0xFFFFFFFFu);
+              const double alpha = group_min<G>(amin);
+              const unsigned ibd = group_min_u32<G>(amin == alpha && alpha < 1.0 ? imin : 0xFFFFFFFFu);
 #pragma unroll
               for (int j = 0; j < J; ++j) {
                 if (iwhere[j] <= 0) {
-                  if (alpha < 1.0 && (unsigned)(lane + kWave * j) == ibd) {
-                    double lo, hi;
-                    slot_bounds<J>(q, j, code[j], lo, hi);
-                    if (d[j] > 0.0) { z[j] = hi; d[j] = 0.0; }
-                    else if (d[j] < 0.0) { z[j] = lo; d[j] = 0.0; }
+                  const unsigned idx = (unsigned)((j / 3) * n3 + 3 * k + (j % 3));
+                  if (alpha < 1.0 && idx == ibd) {
+                    if (d[j] > 0.0) { z[j] = box_hi(q, j); d[j] = 0.0; }
+                    else if (d[j] < 0.0) { z[j] = box_lo(q, j); d[j] = 0.0; }
                   }
                   z[j] += alpha * d[j];
                 }
@@ -1098,7 +1070,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
     for (int j = 0; j < J; ++j) { d[j] = z[j] - x[j]; dtdp += d[j] * d[j]; gd0p += g[j] * d[j]; }
     double r2[2] = {dtdp, gd0p};
-    wave_sum_n<2>(r2);
+    group_sum_n<G, 2>(r2);
     const double dtd = r2[0];
     gd_fused = r2[1];                                         // g'd at the start of the search
     double stpmx;
@@ -1107,8 +1079,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       double smx = kBig;
 #pragma unroll
       for (int j = 0; j < J; ++j) {
-        double lo, hi;
-        slot_bounds<J>(q, j, code[j], lo, hi);
+        const double lo = box_lo(q, j), hi = box_hi(q, j);
         const double a1 = d[j];
         const bool neg = a1 < 0.0, pos = a1 > 0.0;
         const double a2 = neg ? lo - x[j] : hi - x[j];
@@ -1117,11 +1088,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         const double quot = a2 / a1;
         smx = blocked ? 0.0 : (tighter ? quot : smx);
       }
-      stpmx = wave_min(smx);
+      stpmx = group_min<G>(smx);
     }
     double stp = 1.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) { xo[j] = x[j]; go[j] = g[j]; }
+    for (int j = 0; j < J; ++j) xo[j] = opaque(x[j]);
     SE3MPC_TICK(13)
     fold = f;
     int ifun = 0, iback = 0, ls_info = 0;
@@ -1140,22 +1111,29 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       if (lt == LS_ERROR) { ls_info = -4; break; }          // dcsrch rejected its inputs (never with a feasible d)
       ++ifun; iback = ifun - 1;
       if (iback >= q.maxls) break;
+      // the trial point; `moved`: it differs from the x of the last evaluation (which the registers still hold)
+      bool moved = false;
       if (stp == 1.0) {
 #pragma unroll
-        for (int j = 0; j < J; ++j) x[j] = z[j];
+        for (int j = 0; j < J; ++j) { moved = moved | !(z[j] == x[j]); x[j] = z[j]; }
       } else {
 #pragma unroll
-        for (int j = 0; j < J; ++j) x[j] = stp * d[j] + xo[j];
+        for (int j = 0; j < J; ++j) { const double xn = stp * (z[j] - xo[j]) + xo[j]; moved = moved | !(xn == x[j]); x[j] = xn; }
       }
+      if (!x_is_last || group_ballot<G>(moved) != 0ull) ++nfev;
+      x_is_last = true;
       SE3MPC_TICK(4)
       f = eval_fg(true);
       SE3MPC_TICK(1)
     }
     SE3MPC_TICK(4)
     if (ls_info != 0 || iback >= q.maxls) {
-      // restore the previous iterate
+      // restore the previous iterate (its gradient recomputed).  x held the x of the last evaluation, or the iterate itself when
+      // this search evaluated nothing; after the restore it still does only if the two are the same point.
+      bool differs = false;
 #pragma unroll
-      for (int j = 0; j < J; ++j) { x[j] = xo[j]; g[j] = go[j]; }
+      for (int j = 0; j < J; ++j) { differs = differs | !(x[j] == xo[j]); x[j] = xo[j]; g[j] = grad_of(j, xo[j]); }     // (g was not touched by the search: this is what it holds already, bit for bit)
+      if (group_ballot<G>(differs) != 0ull) x_is_last = false;
       f = fold;
       if (col == 0) { task = SE3MPC_TASK_ABNORMAL; status = 2; break; }
       col = 0; theta = 1.0; iupdat = 0;
@@ -1164,6 +1142,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 
     // ===================================================================== new iterate
     ++iter; ++nit;
+#pragma unroll
+    for (int j = 0; j < J; ++j) g[j] = grad_of(j, x[j]);      // the gradient at the accepted point (the search's evaluations did not store it)
     sbgnrm = projgr();
     if (nit >= q.maxiter) { task = SE3MPC_TASK_STOP_MAXITER; status = 1; break; }
     if (nfev > q.maxfun) { task = SE3MPC_TASK_STOP_MAXFUN; status = 1; break; }
@@ -1172,11 +1152,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       const double ddum = fmax(fabs(fold), fmax(fabs(f), 1.0));
       if ((fold - f) <= q.ftol * ddum) { task = SE3MPC_TASK_CONV_FTOL; status = 0; break; }
     }
-    // ---- BFGS update (matupd + formt)
+    // ---- BFGS update (matupd + formt); d is formed again from x_old, then xo becomes y = g - g(x_old)
     double rrp = 0.0;
 #pragma unroll
-    for (int j = 0; j < J; ++j) { go[j] = g[j] - go[j]; rrp += go[j] * go[j]; }   // go = y
-    const double rr = wave_sum(rrp);
+    for (int j = 0; j < J; ++j) { d[j] = z[j] - xo[j]; xo[j] = g[j] - grad_of(j, xo[j]); rrp += xo[j] * xo[j]; }
+    const double rr = group_sum<G>(rrp);
     double dr, ddum;
     if (stp == 1.0) { dr = gd - gdold; ddum = -gdold; }
     else {
@@ -1189,37 +1169,37 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     if (iupdat > m && m < q.m) { task = SE3MPC_TASK_OVERFLOW; status = 1; break; }   // second tier re-solves this problem
     if (iupdat <= m) col = iupdat;
     else {
-      // memory full: drop the oldest pair (each lane shifts its own elements; lane 0 the small matrices)
+      // memory full: drop the oldest pair (each lane shifts its own elements; the first lane the small matrices)
       for (int c = 0; c + 1 < m; ++c) {
 #pragma unroll
         for (int j = 0; j < J; ++j) { WS(c, j) = WS(c + 1, j); WY(c, j) = WY(c + 1, j); }
       }
-      if (lane == 0)
+      if (k == 0)
         for (int i = 0; i + 1 < m; ++i)
-          for (int k = 0; k + 1 < m; ++k) { ss[i * m + k] = ss[(i + 1) * m + k + 1]; sy[i * m + k] = sy[(i + 1) * m + k + 1]; }
-      __syncthreads();
+          for (int kk = 0; kk + 1 < m; ++kk) { ss[i * m + kk] = ss[(i + 1) * m + kk + 1]; sy[i * m + kk] = sy[(i + 1) * m + kk + 1]; }
+      group_sync<G>();
     }
 #pragma unroll
-    for (int j = 0; j < J; ++j) { WS(col - 1, j) = (IO)d[j]; WY(col - 1, j) = (IO)go[j]; }
+    for (int j = 0; j < J; ++j) { WS(col - 1, j) = (IO)d[j]; WY(col - 1, j) = (IO)xo[j]; }
     theta = rr / dr;
     bool formt_failed;
     if (col <= kFastCol) {
       // matupd's new row / column and formt on registers: every lane forms theta*S'S + L D^-1 L' and its Cholesky factor from
-      // wave-uniform values; lane 0 writes the state (sy, ss, wt) back for the next iteration
+      // group-uniform values; the first lane writes the state (sy, ss, wt) back for the next iteration
       auto update_fast = [&](auto tag) {
         constexpr int C = decltype(tag)::value;
         double syr[C][C], ssr[C][C], wtr[C][C];
 #pragma unroll
         for (int i = 0; i < C; ++i)
 #pragma unroll
-          for (int k = 0; k < C; ++k) { syr[i][k] = (k <= i && i < C - 1) ? sy[i * m + k] : 0.0; ssr[i][k] = (k >= i && k < C - 1) ? ss[i * m + k] : 0.0; wtr[i][k] = 0.0; }
+          for (int kk = 0; kk < C; ++kk) { syr[i][kk] = (kk <= i && i < C - 1) ? sy[i * m + kk] : 0.0; ssr[i][kk] = (kk >= i && kk < C - 1) ? ss[i * m + kk] : 0.0; wtr[i][kk] = 0.0; }
 #pragma unroll
         for (int c = 0; c + 1 < C; ++c) {
           double a1 = 0.0, a2 = 0.0;
 #pragma unroll
           for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
           double r2[2] = {a1, a2};
-          wave_sum_n<2>(r2);
+          group_sum_n<G, 2>(r2);
           syr[C - 1][c] = r2[0]; ssr[c][C - 1] = r2[1];
         }
         ssr[C - 1][C - 1] = (stp == 1.0) ? dtd : stp * stp * dtd;
@@ -1234,12 +1214,12 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             const int k1 = i < jj ? i : jj;
             double dd = 0.0;
 #pragma unroll
-            for (int k = 0; k < C; ++k) if (k < k1) dd += syr[i][k] * syr[jj][k] / syr[k][k];
+            for (int kk = 0; kk < C; ++kk) if (kk < k1) dd += syr[i][kk] * syr[jj][kk] / syr[kk][kk];
             wtr[i][jj] = dd + theta * ssr[i][jj];
           }
         formt_failed = dpofa_regs<C, 0, C>(wtr) != 0;
-        __syncthreads();
-        if (lane == 0) {
+        group_sync<G>();
+        if (k == 0) {
 #pragma unroll
           for (int c = 0; c < C; ++c) { sy[(C - 1) * m + c] = syr[C - 1][c]; ss[c * m + (C - 1)] = ssr[c][C - 1]; }
 #pragma unroll
@@ -1247,7 +1227,7 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
             for (int jj = 0; jj < C; ++jj) if (jj >= i) wt[i * m + jj] = wtr[i][jj];
         }
-        __syncthreads();
+        group_sync<G>();
       };
       if (col == 1) update_fast(ColTag<1>{}); else update_fast(ColTag<2>{});
     } else {
@@ -1255,10 +1235,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
         double a1 = 0.0, a2 = 0.0;
   #pragma unroll
         for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
-        a1 = wave_sum(a1); a2 = wave_sum(a2);
-        if (lane == 0) { sy[(col - 1) * m + c] = a1; ss[c * m + (col - 1)] = a2; }
+        a1 = group_sum<G>(a1); a2 = group_sum<G>(a2);
+        if (k == 0) { sy[(col - 1) * m + c] = a1; ss[c * m + (col - 1)] = a2; }
       }
-      if (lane == 0) {
+      if (k == 0) {
         ss[(col - 1) * m + (col - 1)] = (stp == 1.0) ? dtd : stp * stp * dtd;
         sy[(col - 1) * m + (col - 1)] = dr;
         // formt: T = theta*S'S + L D^-1 L', Cholesky factor in wt
@@ -1267,14 +1247,14 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           for (int jj = i; jj < col; ++jj) {
             const int k1 = i < jj ? i : jj;
             double dd = 0.0;
-            for (int k = 0; k < k1; ++k) dd += sy[i * m + k] * sy[jj * m + k] / sy[k * m + k];
+            for (int kk = 0; kk < k1; ++kk) dd += sy[i * m + kk] * sy[jj * m + kk] / sy[kk * m + kk];
             wt[i * m + jj] = dd + theta * ss[i * m + jj];
           }
         sc[0] = (double)dpofa(wt, m, col);
       }
-      __syncthreads();
+      group_sync<G>();
       formt_failed = sc[0] != 0.0;
-      __syncthreads();
+      group_sync<G>();
     }
     if (formt_failed) { col = 0; theta = 1.0; iupdat = 0; }
 
@@ -1282,12 +1262,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 
   SE3MPC_TICK(5)
   // ===================================================================== results
+  if (live) {
 #pragma unroll
-  for (int j = 0; j < J; ++j) {
-    const int r = lane + kWave * (j % JB);
-    if (r < n3) Xg[(size_t)pb * n + (j / JB) * n3 + r] = (IO)x[j];
+    for (int j = 0; j < J; ++j) Xg[(size_t)pb * n + (j / 3) * n3 + 3 * k + (j % 3)] = (IO)x[j];
   }
-  if (lane == 0 && infog != nullptr) {
+  if (k == 0 && infog != nullptr) {
     se3mpc_solve_info r;
     r.fun = f; r.nit = nit; r.nfev = nfev; r.status = status; r.task = task;
     infog[pb] = r;
@@ -1296,24 +1275,15 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   // place wants the accelerations but no attitudes / rates / thrust magnitudes: no frames to build
   const bool want_frames = attg != nullptr || ratesg != nullptr || thrustg != nullptr;
   if (!want_frames && accg == nullptr) return;
-  // ---- _extract_solution_from_result (planner.py:582-654): T block -> LDS, lane k = step k
-  __syncthreads();
-#pragma unroll
-  for (int j = 2 * JB; j < J; ++j) {
-    const int r = lane + kWave * (j % JB);
-    if (r < n3) {
-      if (want_frames) scratch[r] = x[j];
-      if (accg != nullptr) accg[(size_t)pb * 3 * N + r] = (IO)(x[j] / q.mass - (((code[j] >> 2) & 3) == 2 ? q.grav : 0.0));
-    }
+  // ---- _extract_solution_from_result (planner.py:582-654): lane k = step k holds T_k in its own registers
+  const double t0 = x[6], t1 = x[7], t2 = x[8];
+  if (live && accg != nullptr) {
+    const size_t o = (size_t)pb * n3 + 3 * k;
+    accg[o] = (IO)(t0 / q.mass); accg[o + 1] = (IO)(t1 / q.mass); accg[o + 2] = (IO)(t2 / q.mass - q.grav);
   }
   if (!want_frames) return;
-  __syncthreads();
-  double* Rm = scratch + 3 * kWave;       // [9][64]: b1, b2, b3 of every step
-  const bool have = lane < N;
-  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
-  if (have) { t0 = scratch[3 * lane]; t1 = scratch[3 * lane + 1]; t2 = scratch[3 * lane + 2]; }
   const double mag = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
-  const bool valid = have && mag > 1e-6;
+  const bool valid = live && mag > 1e-6;
   double b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
   double roll = 0.0, pitch = 0.0, yaw = 0.0;
   if (valid) {
@@ -1328,31 +1298,31 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     pitch = asin(fmin(fmax(-b1[2], -1.0), 1.0));
     yaw = n1 > 1e-6 ? (b1[1] == 0.0 ? b1[1] : copysign(1.5707963267948966, b1[1])) : 0.0;   // atan2(b1y, b1x) with b1x exactly 0, or b1 = (1,0,0)
   }
-  for (int c = 0; c < 3; ++c) { Rm[c * kWave + lane] = b1[c]; Rm[(3 + c) * kWave + lane] = b2[c]; Rm[(6 + c) * kWave + lane] = b3[c]; }
-  __syncthreads();
-  // prev_R of step k = R of the nearest earlier step with |T| > 1e-6 (planner.py:641-650)
-  const uint64_t vmask = wave_ballot(valid);
-  const uint64_t below = vmask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+  // prev_R of step k = R of the nearest earlier step with |T| > 1e-6 (planner.py:641-650): fetched from that step's lane
+  const uint64_t vmask = group_ballot<G>(valid);
+  const uint64_t below = vmask & ((k == 0) ? 0ull : (~0ull >> (64 - k)));
+  const bool has_prev = valid && below != 0ull;
+  const int pk = has_prev ? 63 - __builtin_clzll(below) : k;          // lane of the group that holds the previous frame (itself: unused)
+  double q1[3], q2[3], q3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { q1[c] = group_gather<G>(b1[c], pk); q2[c] = group_gather<G>(b2[c], pk); q3[c] = group_gather<G>(b3[c], pk); }
   double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-  if (valid && below != 0ull) {
-    const int pk = 63 - __builtin_clzll(below);
-    const double inv_dt = 1.0 / q.dt;
+  if (has_prev) {
     double d1[3], d2[3], d3[3];
     for (int c = 0; c < 3; ++c) {
-      d1[c] = (b1[c] - Rm[c * kWave + pk]) / q.dt;
-      d2[c] = (b2[c] - Rm[(3 + c) * kWave + pk]) / q.dt;
-      d3[c] = (b3[c] - Rm[(6 + c) * kWave + pk]) / q.dt;
+      d1[c] = (b1[c] - q1[c]) / q.dt;
+      d2[c] = (b2[c] - q2[c]) / q.dt;
+      d3[c] = (b3[c] - q3[c]) / q.dt;
     }
-    (void)inv_dt;
     w0 = b3[0] * d2[0] + b3[1] * d2[1] + b3[2] * d2[2];
     w1 = b1[0] * d3[0] + b1[1] * d3[1] + b1[2] * d3[2];
     w2 = b2[0] * d1[0] + b2[1] * d1[1] + b2[2] * d1[2];
   }
-  if (have) {
-    const size_t o = (size_t)pb * 3 * N + 3 * lane;
+  if (live) {
+    const size_t o = (size_t)pb * n3 + 3 * k;
     if (attg != nullptr) { attg[o] = (IO)roll; attg[o + 1] = (IO)pitch; attg[o + 2] = (IO)yaw; }
     if (ratesg != nullptr) { ratesg[o] = (IO)w0; ratesg[o + 1] = (IO)w1; ratesg[o + 2] = (IO)w2; }
-    if (thrustg != nullptr) thrustg[(size_t)pb * N + lane] = (IO)mag;
+    if (thrustg != nullptr) thrustg[(size_t)pb * N + k] = (IO)mag;
   }
 #ifdef SE3MPC_SOLVE_PROFILE
   __syncthreads();
@@ -1366,14 +1336,25 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #endif
 }
 
-static int g_solver_variant = 0;   // bit 0: published sequential Cauchy search also while the memory is empty
+static int g_solver_variant = 0;   // bit 0: published sequential Cauchy search also while the memory is empty; bits 8-15: forced group size (0 = automatic)
 
-static size_t solve_lds_bytes(int m, int J, size_t io_size) {
-  const size_t doubles = (size_t)3 * m * m + 4 * m * m + 5 * 2 * m + 8 + (size_t)kWave * J;
-  size_t pairs = (size_t)2 * m * kWave * J * io_size;
-  const size_t scratch = (size_t)12 * kWave * sizeof(double);
-  if (pairs < scratch) pairs = scratch;
-  return doubles * sizeof(double) + pairs;
+static size_t solve_lds_bytes(int m, int G, size_t io_size) {
+  const size_t P = kWave / G;
+  const size_t pairs = (size_t)2 * m * kSlots * kWave * io_size;
+  return P * small_doubles(m) * sizeof(double) + pairs;
+}
+
+// Group size for problems of horizon N: the smallest group that holds the horizon packs the most problems into a wavefront -- the
+// group-uniform algebra (line search, middle matrices, reductions) is then shared by 64 / G problems.  Measured on MI355X
+// (profiles/r03_solve_group_probe.txt): the smallest group wins at every batch size from 1 K problems up, also where a wider group
+// would put more wavefronts on the chip (N = 6: 1 K / 4 K / 8 K / 64 K problems take 32 / 37 / 48 / 180 us at G = 8 against
+// 33 / 48 / 51 / 335 us at G = 16); the cost of co-resident problems diverging (a problem that stops after one iteration waits for
+// its neighbours' third) is about an eighth of a wavefront's time.
+static int solve_group_size(int N) {
+  const int forced = (g_solver_variant >> 8) & 0xFF;
+  const int G = N <= 8 ? 8 : (N <= 16 ? 16 : (N <= 32 ? 32 : 64));
+  if (forced == 8 || forced == 16 || forced == 32 || forced == 64) return forced >= G ? forced : G;
+  return G;
 }
 
 template <typename IO>
@@ -1387,22 +1368,32 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   if (!p0 || !v0 || !X || (p->has_goal && !goal)) return SE3MPC_ERR_NULL;
   SolveDev q = make_solve_dev(*p);
   q.seq_cauchy = g_solver_variant & 1;
-  const int JB = (3 * q.N + kWave - 1) / kWave;           // register slots per block of the decision vector (slot layout above)
-  if (JB > 3) return SE3MPC_ERR_SHAPE;                    // horizon <= 64 (check_params_impl says the same)
+  if (q.N > kWave) return SE3MPC_ERR_SHAPE;               // horizon <= 64 (check_params_impl says the same)
   hipStream_t s = (hipStream_t)stream;
-#define SE3MPC_SOLVE_CASE(JJ)                                                                                            \
-  hipLaunchKernelGGL((solve_kernel<IO, JJ>), dim3(B), dim3(kWave), solve_lds_bytes(q.mlds, JJ, sizeof(IO)), s, q, B, p0, \
+  const int G = solve_group_size(q.N);
+  const int waves = (int)(((long)B * G + kWave - 1) / kWave);
+#define SE3MPC_SOLVE_CASE(GG)                                                                                               \
+  if (solve_lds_bytes(q.mlds, GG, sizeof(IO)) > 64 * 1024)                                                                  \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<IO, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)solve_lds_bytes(q.mlds, GG, sizeof(IO)));                                                 \
+  hipLaunchKernelGGL((solve_kernel<IO, GG>), dim3(waves), dim3(kWave), solve_lds_bytes(q.mlds, GG, sizeof(IO)), s, q, B, p0, \
                      v0, goal, x0, X, info, acc, att, rates, thrust)
 #define SE3MPC_SOLVE_LAUNCH()               \
-  if (JB == 1) SE3MPC_SOLVE_CASE(3);        \
-  else if (JB == 2) SE3MPC_SOLVE_CASE(6);   \
-  else SE3MPC_SOLVE_CASE(9)
-  constexpr int kFastPairs = 4;
-  // Two tiers buy occupancy (two resident solves per SIMD instead of one); up to one wavefront per SIMD of
-  // the chip (256 CUs x 4) there is nothing to buy, and a single launch with the full memory is quicker.
-  constexpr int kOneTierProblems = 1024;
-  const bool two_tier = info != nullptr && q.m > kFastPairs && B > kOneTierProblems;    // the tiers talk through info[].task
-  q.mlds = two_tier ? kFastPairs : q.m;
+  if (G == 8) { SE3MPC_SOLVE_CASE(8); }         \
+  else if (G == 16) { SE3MPC_SOLVE_CASE(16); }  \
+  else if (G == 32) { SE3MPC_SOLVE_CASE(32); }  \
+  else { SE3MPC_SOLVE_CASE(64); }
+  // Two tiers buy occupancy (two resident wavefronts per SIMD): the first gets the most pairs (<= 4, >= 2) whose LDS still lets
+  // eight wavefronts share a CU's 160 KiB.  While every wavefront of the launch is resident at once even with the full memory's LDS
+  // footprint (256 CUs x the wavefronts whose LDS fits a CU, at most one per SIMD) there is nothing to buy, and a single launch
+  // with the full memory is quicker.
+  constexpr size_t kLdsPerCu = 160 * 1024;
+  int fast = 4;
+  while (fast > 2 && solve_lds_bytes(fast, G, sizeof(IO)) > kLdsPerCu / 8) --fast;
+  size_t full_per_cu = kLdsPerCu / solve_lds_bytes(q.m, G, sizeof(IO));
+  if (full_per_cu > 4) full_per_cu = 4;
+  const bool two_tier = info != nullptr && q.m > fast && (size_t)waves > 256 * full_per_cu;    // the tiers talk through info[].task
+  q.mlds = two_tier ? fast : q.m;
   SE3MPC_SOLVE_LAUNCH();
   rc = launch_status("se3mpc_solve");
   if (rc != SE3MPC_OK || !two_tier) return rc;
@@ -1419,7 +1410,8 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
 using namespace se3mpc;
 
 extern "C" int se3mpc_set_solver_variant(int variant) {
-  if (variant < 0 || variant > 1) return SE3MPC_ERR_SHAPE;
+  const int forced = (variant >> 8) & 0xFF;
+  if (variant < 0 || (variant & ~0xFF01) != 0 || !(forced == 0 || forced == 8 || forced == 16 || forced == 32 || forced == 64)) return SE3MPC_ERR_SHAPE;
   se3mpc::g_solver_variant = variant;
   return SE3MPC_OK;
 }

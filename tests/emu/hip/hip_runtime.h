@@ -44,6 +44,8 @@ inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 0; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { p->gcnArchName[0] = 0; return hipSuccess; }
+constexpr int hipFuncAttributeMaxDynamicSharedMemorySize = 8;
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 
 namespace emu {
@@ -115,6 +117,31 @@ inline T exchange(T v, int src_lane_in_block) {
   return out;
 }
 
+// rendezvous of the `size` lanes [base, base + size) only: groups of a wavefront that sit in different branches of divergent control
+// flow (the packed solver: one problem per aligned group of 8 / 16 / 32 lanes).  All lanes of a group run the same control flow and
+// return together, so a group's count is simply `size`.
+inline unsigned g_group_arrived[1024], g_group_generation[1024];
+inline void sync_group(int base, int size) {
+  if (size >= (int)g_blockDim.x && base == 0 && g_live == (int)g_blockDim.x) { sync(); return; }
+  const unsigned gen = g_group_generation[base];
+  if (++g_group_arrived[base] >= (unsigned)size) { g_group_arrived[base] = 0; ++g_group_generation[base]; return; }
+  while (g_group_generation[base] == gen) yield_to_next();
+}
+template <typename T>
+inline T exchange_group(T v, int src_lane_in_block, int base, int size) {
+  static_assert(sizeof(T) <= 8, "emu shuffle: <= 8 bytes");
+  const unsigned me = g_fibers[g_cur].tid.x;
+  unsigned long long raw = 0;
+  std::memcpy(&raw, &v, sizeof(T));
+  g_slots[me] = raw;
+  sync_group(base, size);
+  unsigned long long got = (src_lane_in_block >= base && src_lane_in_block < base + size) ? g_slots[src_lane_in_block] : raw;
+  sync_group(base, size);
+  T out;
+  std::memcpy(&out, &got, sizeof(T));
+  return out;
+}
+
 template <typename K, typename... Args>
 void launch(K kernel, dim3 grid, dim3 block, Args... args) {
   constexpr size_t kStack = 1 << 20;
@@ -125,6 +152,7 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
     for (unsigned bx = 0; bx < grid.x; ++bx) {
       g_blockIdx = dim3(bx, by);
       g_arrived = 0; g_generation = 0; g_live = (int)block.x;
+      std::memset(g_group_arrived, 0, sizeof(g_group_arrived)); std::memset(g_group_generation, 0, sizeof(g_group_generation));
       for (unsigned t = 0; t < block.x; ++t) {
         Fiber& f = g_fibers[t];
         f.tid = dim3(t); f.done = false;

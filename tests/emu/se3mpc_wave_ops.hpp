@@ -35,6 +35,35 @@ inline int first_lane(uint64_t mask) { return mask ? __builtin_ctzll(mask) : -1;
 inline double wave_bcast(double v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
 inline float wave_bcast(float v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
 inline int wave_bcast(int v, int src) { return ::emu::exchange(v, (int)threadIdx.x - (int)(threadIdx.x % 64) + src); }
+// ---- sub-wavefront groups (product header: DPP butterflies / v_permlane16_swap; here: rendezvous of the group's fibers only)
+template <int G, typename T, typename OP>
+inline T emu_group_reduce(T v, OP op) {
+  const int base = (int)threadIdx.x - (int)(threadIdx.x % G);
+  T acc{};
+  for (int l = 0; l < G; ++l) {
+    T x = ::emu::exchange_group(v, base + l, base, G);
+    acc = (l == 0) ? x : op(acc, x);
+  }
+  return acc;
+}
+template <int G> inline double group_sum(double v) { return emu_group_reduce<G>(v, [](double a, double b) { return a + b; }); }
+template <int G, int K> inline void group_sum_n(double (&v)[K]) { for (int k = 0; k < K; ++k) v[k] = group_sum<G>(v[k]); }
+template <int G> inline double group_max(double v) { return emu_group_reduce<G>(v, [](double a, double b) { return a > b ? a : b; }); }
+template <int G> inline double group_min(double v) { return emu_group_reduce<G>(v, [](double a, double b) { return a < b ? a : b; }); }
+template <int G> inline uint32_t group_min_u32(uint32_t v) { return emu_group_reduce<G>(v, [](uint32_t a, uint32_t b) { return a < b ? a : b; }); }
+template <int G> inline int group_sum_i32(int v) { return emu_group_reduce<G>(v, [](int a, int b) { return a + b; }); }
+template <int G>
+inline uint64_t group_ballot(bool pred) {
+  uint64_t m = 0;
+  const int base = (int)threadIdx.x - (int)(threadIdx.x % G);
+  for (int l = 0; l < G; ++l) m |= (uint64_t)(::emu::exchange_group<int>(pred ? 1 : 0, base + l, base, G) & 1) << l;
+  return m;
+}
+template <int G> inline int group_bcast(int v, int src) { const int base = (int)threadIdx.x - (int)(threadIdx.x % G); return ::emu::exchange_group(v, base + src, base, G); }
+template <int G> inline double group_bcast(double v, int src) { const int base = (int)threadIdx.x - (int)(threadIdx.x % G); return ::emu::exchange_group(v, base + src, base, G); }
+template <int G> inline double group_gather(double v, int src) { const int base = (int)threadIdx.x - (int)(threadIdx.x % G); return ::emu::exchange_group(v, base + src, base, G); }
+template <int G> inline void group_sync() { ::emu::sync_group((int)threadIdx.x - (int)(threadIdx.x % G), G); }
+
 template <typename R>
 struct LaneBuf { const char* base; };
 template <typename R>

@@ -401,8 +401,15 @@ def solve_params(c) -> Params:
                                      ftol=10 * c["tol"])
 
 
-def check_solver_golden(h: Harness, data, meta, keys=None, thrust_tol=None):
-    """The batched solve against what the reference itself returned (tests/golden/solve_cases)."""
+def check_solver_golden(h: Harness, data, meta, keys=None, thrust_tol=None, group=None):
+    """The batched solve against what the reference itself returned (tests/golden/solve_cases).
+    group: force the solver's lanes-per-problem (cases whose horizon does not fit the group run at the smallest group that holds it)."""
+    if group is not None:
+        h.ops.lib.set_solver_variant(int(group) << 8)
+        try:
+            return check_solver_golden(h, data, meta, keys=keys, thrust_tol=thrust_tol)
+        finally:
+            h.ops.lib.set_solver_variant(0)
     t = dict(h.tol)
     if thrust_tol is not None:
         t["thrust"] = thrust_tol
@@ -500,24 +507,42 @@ def check_solver_extraction(h: Harness, N: int, B: int, seed: int = 3):
     vec_close(h.to_host(out2["x"]).astype(float), np.clip(ref0, b[:, 0], b[:, 1]), 10 * h.tol["vec_rel"], "cold start")
 
 
-def check_solver_vs_oracle(h: Harness, N: int, B: int, seed: int = 11, **overrides):
+def check_solver_vs_oracle(h: Harness, N: int, B: int, seed: int = 11, group=None, **overrides):
     """Random problems of the cfg-2 distribution: batched HIP solve vs the oracle (SciPy) one by one.
-    Returns (max position error, fraction of problems whose nit/nfev/status differ)."""
+    Returns (max position error over ALL problems that end at SciPy's point, fraction of problems whose nit/nfev/status differ).
+    The assertion is unconditional: a problem whose counts differ from SciPy's (a line-search branch decided by the last bits of a
+    float32 input, say) must still end within the position tolerance of SciPy's result OR at an objective value no worse than
+    SciPy's (f_gpu <= f_scipy * (1 + 1e-6)): it may take another path, it may not return something worse.
+    group: force the solver's lanes-per-problem (8 / 16 / 32 / 64; None = the library's own choice for this batch)."""
     rng = np.random.default_rng(seed)
     prm = Params.reference_defaults(horizon=N, **overrides)
     cfg = oracle_cfg(prm)
     p0, v0, goal, _ = random_batch(rng, B, N)
-    out = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
-    info = h.ops.info_to_host(out["info"])
-    X = h.to_host(out["x"]).astype(float)
+    if group is not None:
+        h.ops.lib.set_solver_variant(int(group) << 8)
+    try:
+        out = h.ops.solve(prm, h.prob(p0), h.prob(v0), h.prob(goal))
+        info = h.ops.info_to_host(out["info"])
+        X = h.to_host(out["x"]).astype(float)
+    finally:
+        if group is not None:
+            h.ops.lib.set_solver_variant(0)
     worst, mism = 0.0, 0
     for i in range(B):
         xr, ir = orc.solve(p0[i].astype(h.dt).astype(float), v0[i].astype(h.dt).astype(float),
                            goal[i].astype(h.dt).astype(float), cfg)
         same = (int(info["nit"][i]), int(info["nfev"][i]), int(info["status"][i])) == (ir["nit"], ir["nfev"], ir["status"])
+        err = float(np.max(np.abs(X[i, :3 * N] - xr[:3 * N])))
         mism += 0 if same else 1
-        if same:
-            worst = max(worst, float(np.max(np.abs(X[i, :3 * N] - xr[:3 * N]))))
+        if same or err <= h.tol["pos"]:
+            worst = max(worst, err)
+        else:
+            assert float(info["fun"][i]) <= ir["fun"] * (1.0 + 1e-6) + 1e-12, (
+                f"problem {i} (N={N}, seed={seed}): counts {int(info['nit'][i]), int(info['nfev'][i]), int(info['status'][i])} vs SciPy "
+                f"{ir['nit'], ir['nfev'], ir['status']}, {err:.3e} m from SciPy's positions and a worse objective "
+                f"({float(info['fun'][i]):.9g} vs {ir['fun']:.9g})")
+    if mism:
+        print(f"[check_solver_vs_oracle] N={N} B={B} seed={seed} {np.dtype(h.dt).name}: {mism} of {B} problems count differently from SciPy")
     return worst, mism / B
 
 

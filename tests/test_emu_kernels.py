@@ -87,6 +87,23 @@ def test_batched_solve_matches_scipy_odd_horizons(emu_ops):
         assert mism == 0.0 and worst <= 1e-9
 
 
+@pytest.mark.parametrize("group", [8, 16, 32, 64])
+def test_solver_group_sizes(emu_ops, golden_solve, group):
+    """The packed solver: 64 / group problems share a wavefront and run their own control flow.  Every group size on the reference's
+    golden solves (horizons that do not fit a group run at the next size), and batches of random problems -- different iteration
+    counts side by side in one wavefront, a ragged last wavefront -- against SciPy one by one."""
+    data, meta = golden_solve
+    keys = {c["key"] for i, c in enumerate(meta["cases"]) if c["N"] <= group and (i % 3 == 0 or c["tag"] != "random")}
+    assert pc.check_solver_golden(harness(emu_ops, np.float64), data, meta, keys=keys, group=group) <= 1e-9
+    N = {8: 6, 16: 13, 32: 30, 64: 40}[group]
+    B = 2 * (64 // group) + 3 if group < 64 else 3
+    worst, mism = pc.check_solver_vs_oracle(harness(emu_ops, np.float64), N, B, seed=group, group=group)
+    assert mism == 0.0 and worst <= 1e-9
+    if group <= 16:
+        worst, mism = pc.check_solver_vs_oracle(harness(emu_ops, np.float32), N, B, seed=group + 1, group=group)
+        assert mism <= 0.1 and worst <= 1e-4
+
+
 def test_solver_extraction_and_cold_start(emu_ops):
     pc.check_solver_extraction(harness(emu_ops, np.float64), 6, 4)
     pc.check_solver_extraction(harness(emu_ops, np.float32), 20, 3)
@@ -261,4 +278,4 @@ def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
     assert ls("simulator_step", "f64", sp, 2, 0.01, 0, p(tq), 0, 0, p(t), p(z3), p(z3), p(z3), p(z3), 0) == -1
     assert ls("control_plan", "f64", cp, 2, p(t), p(t), p(z3), p(z3), p(z3), p(z3), 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(state), p(th), p(tq), 0, 0, 0, 0, 0) == 0
     assert ls("control_plan", "f64", cp, 2, p(t), 0, p(z3), p(z3), p(z3), p(z3), 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(state), p(th), p(tq), 0, 0, 0, 0, 0) == -1
-    assert lib._dll.se3mpc_set_solver_variant(2) == -3 and lib._dll.se3mpc_set_solver_variant(0) == 0
+    assert lib._dll.se3mpc_set_solver_variant(2) == -3 and lib._dll.se3mpc_set_solver_variant(24 << 8) == -3 and lib._dll.se3mpc_set_solver_variant(0) == 0
