@@ -512,15 +512,26 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
         st = DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.zeros(3))
         rng = np.random.default_rng(0)
         goals = rng.uniform(-5, 5, (240, 3)); goals[:, 2] = np.abs(goals[:, 2]) + 0.5
-        ts = []
+        # plan_trajectory returns host arrays: when it returns, the device work behind them is complete (its launch-and-wait call came back on
+        # the kernel's completion ticket) -- that is the timed call, as the reference's contract test times it.  The same call followed by a
+        # device-wide synchronise (what rounds 1-2 timed) is reported beside it.
+        ts, ts_sync = [], []
+        for i, g in enumerate(goals):
+            t0 = time.perf_counter()
+            pl.plan_trajectory(st, g)
+            t1 = time.perf_counter()
+            if i >= 20:
+                ts.append((t1 - t0) * 1e3)
         for i, g in enumerate(goals):
             t0 = time.perf_counter()
             pl.plan_trajectory(st, g)
             torch.cuda.synchronize()
             if i >= 20:
-                ts.append((time.perf_counter() - t0) * 1e3)
+                ts_sync.append((time.perf_counter() - t0) * 1e3)
         out[f"single_{prec}"] = {"horizon": N, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
-                                 "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(np.max(ts))}
+                                 "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(np.max(ts)),
+                                 "p50_ms_with_device_synchronize": float(np.percentile(ts_sync, 50)),
+                                 "p95_ms_with_device_synchronize": float(np.percentile(ts_sync, 95))}
     # the shooting-form plan through the same mirror: 8192 thrust samples x 16 iterations in one launch, argmin, rollout + extraction of the winner
     if world == 1:
         pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N), precision="f64", device=dev)

@@ -168,6 +168,7 @@ _TYPED_API = {
     "transpose": (False, [_I, _I, _P, _I, _P, _I, _P]),
     "population_sums": (False, [_I, _I, _I, _P, _P, _D, _P, _D, _P, _P, _P]),
     "solve": (True, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "plan_host": (True, [_I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint64, C.c_double, _P]),
 }
 # voxel map: se3mpc_voxel_<base>_<suffix>(const se3mpc_voxel_map*, ...)
 _VOXEL_TYPED_API = {

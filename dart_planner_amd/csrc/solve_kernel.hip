@@ -23,6 +23,7 @@
 // _f32 entry point only stores S, Y and the results in float.
 // No global memory is touched between reading (p0, v0, goal[, x0]) and writing the results.
 #include <hip/hip_runtime.h>
+#include <time.h>
 
 #include "se3mpc_common.hpp"
 #include <se3mpc_wave_ops.hpp>
@@ -408,6 +409,37 @@ __device__ __forceinline__ int formk_factor_regs(double (&wn)[2 * C][2 * C]) {
 template <int C>
 struct ColTag { static constexpr int value = C; };
 
+// A lane's row of one L-BFGS pair in LDS: (s_0, y_0, s_1, y_1, ... s_8, y_8) [+ padding], 16-byte aligned.  Read / written whole with
+// 16-byte DS accesses (ds_read_b128 / ds_write_b128): all of a pass's reads are in flight before the first value is used.
+template <typename IO>
+__device__ __forceinline__ void load_row(const IO* row, IO (&w)[2 * 9]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef IO vec4 __attribute__((ext_vector_type(4)));
+  typedef IO vec2 __attribute__((ext_vector_type(2)));
+  const vec4* r4 = reinterpret_cast<const vec4*>(row);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { const vec4 v = r4[i]; w[4 * i] = v[0]; w[4 * i + 1] = v[1]; w[4 * i + 2] = v[2]; w[4 * i + 3] = v[3]; }
+  const vec2 t = *reinterpret_cast<const vec2*>(row + 16);
+  w[16] = t[0]; w[17] = t[1];
+#else
+  for (int i = 0; i < 18; ++i) w[i] = row[i];
+#endif
+}
+template <typename IO>
+__device__ __forceinline__ void store_row(IO* row, const IO (&w)[2 * 9]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef IO vec4 __attribute__((ext_vector_type(4)));
+  typedef IO vec2 __attribute__((ext_vector_type(2)));
+  vec4* r4 = reinterpret_cast<vec4*>(row);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { vec4 v; v[0] = w[4 * i]; v[1] = w[4 * i + 1]; v[2] = w[4 * i + 2]; v[3] = w[4 * i + 3]; r4[i] = v; }
+  vec2 t; t[0] = w[16]; t[1] = w[17];
+  *reinterpret_cast<vec2*>(row + 16) = t;
+#else
+  for (int i = 0; i < 18; ++i) row[i] = w[i];
+#endif
+}
+
 // Compiler-only memory barrier (no instruction).  The S, Y pairs are read from LDS in four phases of the subspace step; without this the
 // compiler merges the four reads of every element and keeps all 2 * col * 9 values in registers across the whole section (36 VGPRs in the
 // float kernel, 72 in the double one), which is what pushed the packed kernels over 256 registers.  LDS reads are cheap; spills are not.
@@ -434,6 +466,9 @@ __device__ __forceinline__ double box_hi(const SolveDev& q, int j) { return j < 
 // doubles of LDS per problem for the small matrices with storage for m pairs: sy, ss, wt [m][m], wn [2m][2m], pv, cv, vv, wbp, wv [2m],
 // sc [8]; made odd so that the broadcast reads of the (up to eight) problems of a wavefront fall into different banks
 __host__ __device__ constexpr int small_doubles(int m) { return (7 * m * m + 10 * m + 8) | 1; }
+// values per lane and pair in the S, Y image (see the kernel's LDS carve-up), and where the image starts (16-byte aligned)
+template <typename IO> __host__ __device__ constexpr int pair_row_values() { return sizeof(IO) == 4 ? 20 : 18; }
+__host__ __device__ constexpr size_t pairs_offset_bytes(int P, int m) { return ((size_t)P * small_doubles(m) * sizeof(double) + 15) / 16 * 16; }
 
 // 2nd launch-bounds argument = wavefronts per SIMD the register allocation must leave room for: two
 // resident wavefronts per SIMD (<= 256 VGPR+AGPR each) overlap each other's DPP/LDS latencies.
@@ -441,7 +476,8 @@ template <typename IO, int G>
 __global__ void __launch_bounds__(64, SE3MPC_SOLVE_WAVES)
 solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict__ v0g, const IO* __restrict__ goalg,
              const IO* __restrict__ x0g, IO* __restrict__ Xg, se3mpc_solve_info* __restrict__ infog,
-             IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg) {
+             IO* __restrict__ accg, IO* __restrict__ attg, IO* __restrict__ ratesg, IO* __restrict__ thrustg,
+             unsigned long long* doneg, unsigned long long ticket) {
   HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
   constexpr int P = kWave / G, J = kSlots;
   const int lane = lane_id();
@@ -468,8 +504,12 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   double* wbp = vv + 2 * m;                            // [2m]  row of W at a breakpoint
   double* wv = wbp + 2 * m;                            // [2m]  subspace rhs
   double* sc = wv + 2 * m;                             // [8]   scalars handed out of scalar sections
-  IO* ws = reinterpret_cast<IO*>(reinterpret_cast<double*>(lds_raw) + P * small_doubles(m));   // [m][9][64]
-  IO* wy = ws + m * J * kWave;                         // [m][9][64]
+  // pairs: [m][64 lanes][LS] -- a lane's row of one pair holds its nine (s_j, y_j) couples contiguously (18 values + padding to a
+  // multiple of 16 bytes whose dword stride, 20 for float / 36 for double, keeps 16-byte reads of the 16 lanes of a group in
+  // disjoint banks): one pass over a pair is five (float) or nine (double) ds_read_b128 per lane instead of eighteen ds_read_b32,
+  // each of which the register-starved schedule waited for on its own (SQ_WAIT_ANY was 45 % of a lone wavefront's cycles).
+  constexpr int LS = pair_row_values<IO>();
+  IO* pairs = reinterpret_cast<IO*>(lds_raw + pairs_offset_bytes(P, m));
 
   // ---- per-lane facts and problem data
   const bool live = k < N;                 // k >= N: padding lane, its nine variables are fixed at 0
@@ -588,8 +628,9 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     mx = live ? mx : 0.0;
     return group_max<G>(mx);
   };
-  auto WS = [&](int c, int j) -> IO& { return ws[(c * J + j) * kWave + lane]; };
-  auto WY = [&](int c, int j) -> IO& { return wy[(c * J + j) * kWave + lane]; };
+  auto ROW = [&](int c) -> IO* { return static_cast<IO*>(__builtin_assume_aligned(pairs + (c * kWave + lane) * LS, 16)); };
+  auto WS = [&](int c, int j) -> IO& { return ROW(c)[2 * j]; };
+  auto WY = [&](int c, int j) -> IO& { return ROW(c)[2 * j + 1]; };
 
   // ---- L-BFGS-B state (identical in every lane of the group)
   int col = 0, iupdat = 0, iter = 0, nit = 0;
@@ -678,8 +719,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
       // p = W'd (2col group reductions), second half scaled by theta
       for (int c = 0; c < col; ++c) {
         double a1 = 0.0, a2 = 0.0;
+        IO w[2 * J];
+        load_row(ROW(c), w);
 #pragma unroll
-        for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+        for (int j = 0; j < J; ++j) { a1 += (double)w[2 * j + 1] * d[j]; a2 += (double)w[2 * j] * d[j]; }
         double r2[2] = {a1, a2};
         group_sum_n<G, 2>(r2);
         a1 = r2[0]; a2 = r2[1];
@@ -762,13 +805,13 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             const double dibp2 = dibp * dibp;
             f1 = f1 + dt * f2 + dibp2 - theta * dibp * zibp;
             f2 = f2 - theta * dibp2;
-            const int ibp = jsel * kWave + (lane - k + src);       // the owner's element inside a pair's [9][64] image
+            const int ibp = (lane - k + src) * LS + 2 * jsel;      // the owner's (s, y) couple inside a pair's [64][LS] image
             // (the middle-matrix product of a crossing runs as a scalar section of the group's first lane for every col: a crossing with
             // pairs in memory is rare -- none in a typical solve -- and its register form was one of the kernel's two pressure peaks)
             if (col > 0) {
               if (k == 0) {
                 for (int i = 0; i < 2 * col; ++i) cv[i] += dt * pv[i];
-                for (int c = 0; c < col; ++c) { wbp[c] = (double)wy[c * J * kWave + ibp]; wbp[col + c] = theta * (double)ws[c * J * kWave + ibp]; }
+                for (int c = 0; c < col; ++c) { wbp[c] = (double)pairs[c * kWave * LS + ibp + 1]; wbp[col + c] = theta * (double)pairs[c * kWave * LS + ibp]; }
                 const int inf = bmv(sy, wt, m, col, wbp, vv);
                 double wmc = 0.0, wmp = 0.0, wmw = 0.0;
                 for (int i = 0; i < 2 * col; ++i) { wmc += cv[i] * vv[i]; wmp += pv[i] * vv[i]; wmw += wbp[i] * vv[i]; }
@@ -828,12 +871,23 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           double sums[3 * C * C];
 #pragma unroll
           for (int i = 0; i < 3 * C * C; ++i) sums[i] = 0.0;
+          // (the rows of all C pairs are needed at once here: 18 C registers in the float kernel; the double kernel with two pairs would
+          // need 72 and reads couple by couple instead -- 16 bytes per read there too)
+          constexpr bool kRows = sizeof(IO) == 4 || C == 1;
+          IO wr_[kRows ? C : 1][2 * J];
+          if constexpr (kRows) {
 #pragma unroll
-          for (int j = 0; j < J; ++j) {                        // slot-outer: a slot's 2C values of S, Y are read once and folded into every cell
+            for (int c = 0; c < C; ++c) load_row(ROW(c), wr_[c]);
+          }
+#pragma unroll
+          for (int j = 0; j < J; ++j) {                        // slot-outer: a slot's 2C values of S, Y are folded into every cell
             const bool fr = iwhere[j] <= 0;
             double wyv[C], wsv[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) { wyv[c] = (double)WY(c, j); wsv[c] = (double)WS(c, j); }
+            for (int c = 0; c < C; ++c) {
+              if constexpr (kRows) { wyv[c] = (double)wr_[c][2 * j + 1]; wsv[c] = (double)wr_[c][2 * j]; }
+              else { wyv[c] = (double)WY(c, j); wsv[c] = (double)WS(c, j); }
+            }
 #pragma unroll
             for (int iy = 0; iy < C; ++iy) {
 #pragma unroll
@@ -872,20 +926,26 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           if (info != 0) return;
           // ---- cmprlb: r = -Z'(B(xcp - x) + g)   (held in d[] on the free variables)
 #pragma unroll
-          for (int j = 0; j < J; ++j) {                        // every variable's value first, ONE select at the end (d stays 0 off the free set)
-            double t = -theta * (z[j] - x[j]) - g[j];
+          for (int j = 0; j < J; ++j) d[j] = -theta * (z[j] - x[j]) - g[j];     // every variable's value first, ONE select at the end (d stays 0 off the free set)
 #pragma unroll
-            for (int c = 0; c < C; ++c) t += (double)WY(c, j) * mc[c] + (double)WS(c, j) * (theta * mc[C + c]);
-            d[j] = (iwhere[j] <= 0) ? t : 0.0;
+          for (int c = 0; c < C; ++c) {                        // pair-outer: one row in registers at a time; per element the additions keep their order
+            IO w[2 * J];
+            load_row(ROW(c), w);
+#pragma unroll
+            for (int j = 0; j < J; ++j) d[j] += (double)w[2 * j + 1] * mc[c] + (double)w[2 * j] * (theta * mc[C + c]);
           }
+#pragma unroll
+          for (int j = 0; j < J; ++j) d[j] = (iwhere[j] <= 0) ? d[j] : 0.0;
           reload_lds();
           // ---- subsm: wv = W'Z d ; wv = K^-1 wv   (d is 0 off the free set: no condition inside the sums)
           double wr[2 * C];
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             double a1 = 0.0, a2 = 0.0;
+            IO w[2 * J];
+            load_row(ROW(c), w);
 #pragma unroll
-            for (int j = 0; j < J; ++j) { a1 += (double)WY(c, j) * d[j]; a2 += (double)WS(c, j) * d[j]; }
+            for (int j = 0; j < J; ++j) { a1 += (double)w[2 * j + 1] * d[j]; a2 += (double)w[2 * j] * d[j]; }
             wr[c] = a1; wr[C + c] = a2;
           }
           group_sum_n<G, 2 * C>(wr);
@@ -992,9 +1052,11 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
             for (int c = 0; c < kFastCol; ++c) {
               if (c < col) {
                 const double b1 = wvr[c] / theta, b2 = wvr[kFastCol + c];
+                IO w[2 * J];
+                load_row(ROW(c), w);
 #pragma unroll
                 for (int j = 0; j < J; ++j) {
-                  const double t = d[j] + ((double)WY(c, j) * b1 + (double)WS(c, j) * b2);
+                  const double t = d[j] + ((double)w[2 * j + 1] * b1 + (double)w[2 * j] * b2);
                   d[j] = (iwhere[j] <= 0) ? t : d[j];
                 }
               }
@@ -1179,8 +1241,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
           for (int kk = 0; kk + 1 < m; ++kk) { ss[i * m + kk] = ss[(i + 1) * m + kk + 1]; sy[i * m + kk] = sy[(i + 1) * m + kk + 1]; }
       group_sync<G>();
     }
+    { IO w[2 * J];
 #pragma unroll
-    for (int j = 0; j < J; ++j) { WS(col - 1, j) = (IO)d[j]; WY(col - 1, j) = (IO)xo[j]; }
+      for (int j = 0; j < J; ++j) { w[2 * j] = (IO)d[j]; w[2 * j + 1] = (IO)xo[j]; }
+      store_row(ROW(col - 1), w); }
     theta = rr / dr;
     bool formt_failed;
     if (col <= kFastCol) {
@@ -1196,8 +1260,10 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 #pragma unroll
         for (int c = 0; c + 1 < C; ++c) {
           double a1 = 0.0, a2 = 0.0;
+          IO w[2 * J];
+          load_row(ROW(c), w);
 #pragma unroll
-          for (int j = 0; j < J; ++j) { a1 += d[j] * (double)WY(c, j); a2 += (double)WS(c, j) * d[j]; }
+          for (int j = 0; j < J; ++j) { a1 += d[j] * (double)w[2 * j + 1]; a2 += (double)w[2 * j] * d[j]; }
           double r2[2] = {a1, a2};
           group_sum_n<G, 2>(r2);
           syr[C - 1][c] = r2[0]; ssr[c][C - 1] = r2[1];
@@ -1274,14 +1340,13 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
   // a restart solve asks for x and info only (every trajectory output null): nothing to extract; a closed loop that reads the plan in
   // place wants the accelerations but no attitudes / rates / thrust magnitudes: no frames to build
   const bool want_frames = attg != nullptr || ratesg != nullptr || thrustg != nullptr;
-  if (!want_frames && accg == nullptr) return;
   // ---- _extract_solution_from_result (planner.py:582-654): lane k = step k holds T_k in its own registers
   const double t0 = x[6], t1 = x[7], t2 = x[8];
   if (live && accg != nullptr) {
     const size_t o = (size_t)pb * n3 + 3 * k;
     accg[o] = (IO)(t0 / q.mass); accg[o + 1] = (IO)(t1 / q.mass); accg[o + 2] = (IO)(t2 / q.mass - q.grav);
   }
-  if (!want_frames) return;
+  if (want_frames) {
   const double mag = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
   const bool valid = live && mag > 1e-6;
   double b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
@@ -1324,6 +1389,13 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
     if (ratesg != nullptr) { ratesg[o] = (IO)w0; ratesg[o + 1] = (IO)w1; ratesg[o + 2] = (IO)w2; }
     if (thrustg != nullptr) thrustg[(size_t)pb * N + k] = (IO)mag;
   }
+  }   // want_frames
+  // se3mpc_plan_host_*: a ONE-wavefront launch tells the waiting host it is done -- every store above made visible to the system, then
+  // the ticket (the first lane of the wavefront belongs to problem 0, which exists; groups of a wavefront reach this point together)
+  if (doneg != nullptr) {
+    __threadfence_system();
+    if (lane == 0) *reinterpret_cast<volatile unsigned long long*>(doneg) = ticket;
+  }
 #ifdef SE3MPC_SOLVE_PROFILE
   __syncthreads();
   SE3MPC_TICK(6)
@@ -1339,9 +1411,8 @@ solve_kernel(SolveDev q, int B, const IO* __restrict__ p0g, const IO* __restrict
 static int g_solver_variant = 0;   // bit 0: published sequential Cauchy search also while the memory is empty; bits 8-15: forced group size (0 = automatic)
 
 static size_t solve_lds_bytes(int m, int G, size_t io_size) {
-  const size_t P = kWave / G;
-  const size_t pairs = (size_t)2 * m * kSlots * kWave * io_size;
-  return P * small_doubles(m) * sizeof(double) + pairs;
+  const size_t pairs = (size_t)m * kWave * (io_size == 4 ? pair_row_values<float>() : pair_row_values<double>()) * io_size;
+  return pairs_offset_bytes(kWave / G, m) + pairs;
 }
 
 // Group size for problems of horizon N: the smallest group that holds the horizon packs the most problems into a wavefront -- the
@@ -1357,9 +1428,12 @@ static int solve_group_size(int N) {
   return G;
 }
 
+// done != nullptr: the host-latency form (se3mpc_plan_host_*): the whole batch must fit ONE wavefront, the kernel stores `ticket`
+// into *done (host-visible memory) as its last act.
 template <typename IO>
 int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const IO* goal, const IO* x0, IO* X,
-               se3mpc_solve_info* info, IO* acc, IO* att, IO* rates, IO* thrust, void* stream) {
+               se3mpc_solve_info* info, IO* acc, IO* att, IO* rates, IO* thrust, void* stream,
+               unsigned long long* done = nullptr, unsigned long long ticket = 0) {
   if (p == nullptr) return SE3MPC_ERR_NULL;
   int rc = check_params_impl(p);
   if (rc) return rc;
@@ -1370,14 +1444,16 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   q.seq_cauchy = g_solver_variant & 1;
   if (q.N > kWave) return SE3MPC_ERR_SHAPE;               // horizon <= 64 (check_params_impl says the same)
   hipStream_t s = (hipStream_t)stream;
-  const int G = solve_group_size(q.N);
+  // (one problem alone in its wavefront runs the whole-wavefront form: its group-uniform values are SGPRs, its branches scalar)
+  const int G = (B == 1 && ((g_solver_variant >> 8) & 0xFF) == 0) ? kWave : solve_group_size(q.N);
   const int waves = (int)(((long)B * G + kWave - 1) / kWave);
+  if (done != nullptr && waves != 1) return SE3MPC_ERR_SHAPE;
 #define SE3MPC_SOLVE_CASE(GG)                                                                                               \
   if (solve_lds_bytes(q.mlds, GG, sizeof(IO)) > 64 * 1024)                                                                  \
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<IO, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                               (int)solve_lds_bytes(q.mlds, GG, sizeof(IO)));                                                 \
   hipLaunchKernelGGL((solve_kernel<IO, GG>), dim3(waves), dim3(kWave), solve_lds_bytes(q.mlds, GG, sizeof(IO)), s, q, B, p0, \
-                     v0, goal, x0, X, info, acc, att, rates, thrust)
+                     v0, goal, x0, X, info, acc, att, rates, thrust, done, ticket)
 #define SE3MPC_SOLVE_LAUNCH()               \
   if (G == 8) { SE3MPC_SOLVE_CASE(8); }         \
   else if (G == 16) { SE3MPC_SOLVE_CASE(16); }  \
@@ -1425,4 +1501,47 @@ extern "C" int se3mpc_solve_f64(const se3mpc_params* p, int B, const double* p0,
                                 const double* x0, double* X, se3mpc_solve_info* info, double* acc, double* att,
                                 double* rates, double* thrust, void* stream) {
   return solve_impl<double>(p, B, p0, v0, goal, x0, X, info, acc, att, rates, thrust, stream);
+}
+
+// Host-latency form of the solve for SE3MPCPlanner.plan_trajectory (planner.py:215-228: one problem, the caller blocks until the plan
+// exists): ONE call launches the solve on the caller's host-pinned, device-mapped buffers and returns when the result is there.
+// Instead of hipStreamSynchronize (an interrupt / signal wait of 10-20 us on top of the kernel) the kernel's last act is a
+// system-scope store of `ticket` into *done, on which this function spins.
+template <typename IO>
+static int plan_host_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const IO* goal, const IO* x0, IO* X,
+                          se3mpc_solve_info* info, IO* acc, IO* att, IO* rates, IO* thrust, unsigned long long* done,
+                          unsigned long long ticket, double timeout_us, void* stream) {
+  if (done == nullptr) return SE3MPC_ERR_NULL;
+  volatile unsigned long long* flag = done;
+  if (*flag == ticket) return SE3MPC_ERR_SHAPE;            // the ticket must differ from what the flag holds
+  const int rc = solve_impl<IO>(p, B, p0, v0, goal, x0, X, info, acc, att, rates, thrust, stream, done, ticket);
+  if (rc != SE3MPC_OK) return rc;
+  if (B == 0) return SE3MPC_OK;
+  timespec t0;
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  for (unsigned spins = 1; *flag != ticket; ++spins) {
+    if ((spins & 255u) == 0) {
+      timespec t1;
+      clock_gettime(CLOCK_MONOTONIC, &t1);
+      if ((double)(t1.tv_sec - t0.tv_sec) * 1e6 + (double)(t1.tv_nsec - t0.tv_nsec) * 1e-3 > timeout_us) {
+        // (a device that does not make the store visible while the host polls, or a very long solve: the ordinary wait)
+        if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return launch_status("se3mpc_plan_host(synchronize)");
+        return *flag == ticket ? SE3MPC_OK : SE3MPC_ERR_LAUNCH;
+      }
+    }
+  }
+  return SE3MPC_OK;
+}
+
+extern "C" int se3mpc_plan_host_f32(const se3mpc_params* p, int B, const float* p0, const float* v0, const float* goal,
+                                    const float* x0, float* X, se3mpc_solve_info* info, float* acc, float* att, float* rates,
+                                    float* thrust, unsigned long long* done, unsigned long long ticket, double timeout_us,
+                                    void* stream) {
+  return plan_host_impl<float>(p, B, p0, v0, goal, x0, X, info, acc, att, rates, thrust, done, ticket, timeout_us, stream);
+}
+extern "C" int se3mpc_plan_host_f64(const se3mpc_params* p, int B, const double* p0, const double* v0, const double* goal,
+                                    const double* x0, double* X, se3mpc_solve_info* info, double* acc, double* att, double* rates,
+                                    double* thrust, unsigned long long* done, unsigned long long ticket, double timeout_us,
+                                    void* stream) {
+  return plan_host_impl<double>(p, B, p0, v0, goal, x0, X, info, acc, att, rates, thrust, done, ticket, timeout_us, stream);
 }

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import logging
 import math
+import ctypes
 import time
 from dataclasses import dataclass, fields
 from typing import Any, Dict, List, Optional, Tuple
@@ -231,8 +232,23 @@ class SE3MPCPlanner(BasePlanner):
                 io["ptr_in"] = (pin, pin + stepb, pin + 2 * stepb)
                 io["ptr_out"] = (base + o_x, base + o_info, base + o_acc, base + o_att, base + o_rates, base + o_thr)
                 io["ptr_x0"] = io["h_x0"].data_ptr()
-        cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
-        stream_handle = None if cur is None else cur.cuda_stream
+                # the host-latency entry point (se3mpc_plan_host_*: launch + spin on a completion word the kernel stores last) serves
+                # batches that fit ONE wavefront: a lone problem, or 64 / lanes-per-problem of them
+                lanes = 64 if B == 1 else (8 if N <= 8 else 16 if N <= 16 else 32 if N <= 32 else 64)
+                io["one_wave"] = B * lanes <= 64
+                io["h_done"] = torch.zeros((8,), dtype=torch.int64, pin_memory=dev.type == "cuda")
+                io["ptr_done"] = io["h_done"].data_ptr()
+                io["ticket"] = 0
+                io["plan_fn"] = getattr(ops.lib._dll, f"se3mpc_plan_host_{suf}")
+                # the launch touches nothing but this planner's own pinned buffers: a stream of its own (no ordering against the caller's
+                # work, no per-plan current-stream lookup)
+                io["plan_stream"] = torch.cuda.Stream(dev) if (io["one_wave"] and dev.type == "cuda") else None
+                io["plan_stream_handle"] = None if io["plan_stream"] is None else io["plan_stream"].cuda_stream
+        if mapped and io["one_wave"]:
+            cur, stream_handle = None, io["plan_stream_handle"]
+        else:
+            cur = torch.cuda.current_stream(dev) if dev.type == "cuda" else None
+            stream_handle = None if cur is None else cur.cuda_stream
         hin = io["h_in_np"]
         hin[0] = p0; hin[1] = v0
         hin[2] = goal if goal is not None else 0.0
@@ -243,8 +259,17 @@ class SE3MPCPlanner(BasePlanner):
                 io["h_x0_np"][...] = x0
                 hx0 = io["h_x0"]
             pin = io["ptr_in"]
-            ops.lib.call("solve", suf, B, pin[0], pin[1], pin[2] if prm.has_goal else 0, io["ptr_x0"] if hx0 is not None else 0, *io["ptr_out"],
-                         stream_handle, params=prm)         # = ops.solve_packed(host_mapped=True) without re-validating the same buffers every plan
+            if io["one_wave"]:
+                # launch + wait in ONE C call (no hipStreamSynchronize: the kernel's last store is the completion ticket the call spins on)
+                io["ticket"] = ticket = io["ticket"] + 1
+                rc = io["plan_fn"](ctypes.byref(prm), B, pin[0], pin[1], pin[2] if prm.has_goal else 0, io["ptr_x0"] if hx0 is not None else 0,
+                                   *io["ptr_out"], io["ptr_done"], ticket, 2000.0, stream_handle)
+                if rc != 0:
+                    ops.lib._check(f"se3mpc_plan_host_{suf}", rc)
+                cur = None                                    # nothing left to wait for
+            else:
+                ops.lib.call("solve", suf, B, pin[0], pin[1], pin[2] if prm.has_goal else 0, io["ptr_x0"] if hx0 is not None else 0, *io["ptr_out"],
+                             stream_handle, params=prm)     # = ops.solve_packed(host_mapped=True) without re-validating the same buffers every plan
         else:
             io["d_in"].copy_(io["h_in"], non_blocking=True)
             dx0 = None if x0 is None else torch.from_numpy(np.ascontiguousarray(x0)).to(device=dev, dtype=dt)

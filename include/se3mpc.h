@@ -555,6 +555,22 @@ int se3mpc_solve_f64(const se3mpc_params* p, int B, const double* p0, const doub
                      const double* x0, double* X, se3mpc_solve_info* info, double* acc, double* att,
                      double* rates, double* thrust, void* stream);
 
+/* Host-latency form of the solve: what SE3MPCPlanner.plan_trajectory (planner.py:215-228, one problem, the caller blocks until the
+ * plan exists) binds.  ONE call = launch + wait: the same arguments as se3mpc_solve_* -- all of them HOST-PINNED, DEVICE-MAPPED
+ * buffers (hipHostMalloc / torch pin_memory): the kernel reads its 72 bytes of input and writes its results in place -- plus
+ *   done    : 8-byte aligned word in host-pinned, device-mapped memory
+ *   ticket  : any value other than *done's current one (a per-call counter)
+ *   timeout_us : after this long the wait falls back to hipStreamSynchronize
+ * The kernel's last act is a system-scope fence and a store of `ticket` into *done; this function spins on that word instead of
+ * paying hipStreamSynchronize's wake-up.  The batch must fit ONE wavefront (B <= 64 / lanes-per-problem: 8 problems at horizon <= 8,
+ * 2 at horizon <= 32, 1 beyond; SE3MPC_ERR_SHAPE otherwise -- use se3mpc_solve_* then).  Returns when the results are in the buffers. */
+int se3mpc_plan_host_f32(const se3mpc_params* p, int B, const float* p0, const float* v0, const float* goal,
+                         const float* x0, float* X, se3mpc_solve_info* info, float* acc, float* att, float* rates,
+                         float* thrust, unsigned long long* done, unsigned long long ticket, double timeout_us, void* stream);
+int se3mpc_plan_host_f64(const se3mpc_params* p, int B, const double* p0, const double* v0, const double* goal,
+                         const double* x0, double* X, se3mpc_solve_info* info, double* acc, double* att, double* rates,
+                         double* thrust, unsigned long long* done, unsigned long long ticket, double timeout_us, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

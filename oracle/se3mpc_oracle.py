@@ -183,6 +183,29 @@ def objective_loops(x, goal, cfg: OracleConfig) -> float:
     return cost
 
 
+def objective_ordered(x, goal, cfg: OracleConfig) -> float:
+    """planner.py:516-550 for ONE problem with the reference's ACCUMULATION ORDER and without its Python loops: the per-step terms are
+    formed vectorised (each `w * np.sum(e_k ** 2)` is the same three-element sum), then added left to right exactly as the reference's
+    `cost += ...` statements run (np.cumsum is sequential).  Bit-identical to :func:`objective_loops` (tests/test_oracle_golden.py), ~20x
+    faster.  This is what :func:`solve` hands to SciPy: L-BFGS-B's line search can turn a last-bit difference of f into another
+    outcome (tests/golden/bifurcation_case: batched np.sum order -> (nit, nfev) = (3, 24), f = 2728.05; the reference's order ->
+    (3, 27), f = 2680.18), so the oracle must not merely equal the reference's objective to 1e-16, it must round like it."""
+    N = cfg.prediction_horizon
+    P, V, T = unpack(np.asarray(x, float), N)
+    terms = []
+    if goal is not None:
+        g = np.asarray(goal, float)
+        terms.append(cfg.position_weight * np.sum((P - g) ** 2, axis=-1))
+    terms.append(cfg.velocity_weight * np.sum(V ** 2, axis=-1))
+    a = T / cfg.mass - np.array([0, 0, cfg.gravity])
+    terms.append(cfg.acceleration_weight * np.sum(a ** 2, axis=-1))
+    d = T - np.array([0, 0, cfg.hover_thrust])
+    terms.append(cfg.thrust_weight * np.sum(d ** 2, axis=-1))
+    if goal is not None:
+        terms.append(np.atleast_1d(10 * cfg.position_weight * np.sum((P[-1] - g) ** 2)))
+    return float(np.cumsum(np.concatenate(terms))[-1])
+
+
 def gradient_loops(x, goal, cfg: OracleConfig) -> np.ndarray:
     """planner.py:552-580 with the reference's loops."""
     N = cfg.prediction_horizon
@@ -295,7 +318,7 @@ def solve(p0, v0, goal, cfg: OracleConfig, x0: Optional[np.ndarray] = None):
         x0 = straight_line_init(p0, v0, goal, cfg)
     b = bounds(cfg)
     g_ = None if goal is None else np.asarray(goal, float)
-    res = minimize(fun=lambda x: float(objective(x, g_, cfg)), x0=x0, method="L-BFGS-B",
+    res = minimize(fun=lambda x: objective_ordered(x, g_, cfg), x0=x0, method="L-BFGS-B",
                    jac=lambda x: gradient(x, g_, cfg), bounds=[(lo, hi) for lo, hi in b],
                    options={"maxiter": cfg.max_iterations, "gtol": cfg.convergence_tolerance,
                             "ftol": cfg.convergence_tolerance * 10, "disp": False})

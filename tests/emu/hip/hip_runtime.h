@@ -209,3 +209,5 @@ inline int atomicAdd(int* p, int v) { int old = *p; *p = old + v; return old; }
 inline int atomicCAS(int* p, int expect, int desired) { int old = *p; if (old == expect) *p = desired; return old; }
 inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { unsigned long long old = *p; *p = old | v; return old; }
 inline void __threadfence() {}
+inline void __threadfence_system() {}
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }

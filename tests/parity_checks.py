@@ -434,6 +434,38 @@ def check_solver_golden(h: Harness, data, meta, keys=None, thrust_tol=None, grou
     return worst
 
 
+def check_solver_bifurcation_case(h: Harness, group=None):
+    """tests/golden/bifurcation_case (make_golden_bifurcation.py): a problem whose outcome hangs on the last bit of an objective
+    value.  The reference ends at (nit, nfev) = (3, 27), f = 2680.18; the other branch, 0.376 m away, at (3, 24), f = 2728.05.  Which
+    side a build of the solver lands on is decided by its own last bits (summation tree, FMA contraction: the MI355X build takes the
+    reference's branch, the host emulation -- sequential sums, no FMA -- the other); what is asserted is that the result IS one of the
+    two outcomes, counts and positions to the usual tolerance.  Returns (branch, position error)."""
+    import json
+    import os
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    data, meta = np.load(os.path.join(gold, "bifurcation_case.npz")), json.load(open(os.path.join(gold, "bifurcation_case.json")))
+    N = meta["N"]
+    prm = Params.reference_defaults(horizon=N, dt=meta["dt"], **meta["weights"])
+    if group is not None:
+        h.ops.lib.set_solver_variant(int(group) << 8)
+    try:
+        out = h.ops.solve(prm, h.prob(data["p0"][None]), h.prob(data["v0"][None]), h.prob(data["goal"][None]))
+        info = h.ops.info_to_host(out["info"])[0]
+        x = h.to_host(out["x"])[0].astype(float)
+    finally:
+        if group is not None:
+            h.ops.lib.set_solver_variant(0)
+    got = (int(info["nit"]), int(info["nfev"]), int(info["status"]))
+    for branch, xkey in (("reference", "x_reference"), ("other_branch", "x_other_branch")):
+        ref = meta[branch]
+        if got == (ref["nit"], ref["nfev"], ref["status"]):
+            assert abs(float(info["fun"]) - ref["fun"]) <= 1e-5 * ref["fun"], (branch, info)
+            err = float(np.max(np.abs(x[:3 * N] - data[xkey][:3 * N])))
+            assert err <= h.tol["pos"], (branch, err)
+            return branch, err
+    raise AssertionError(f"neither of the two published outcomes: {info}")
+
+
 def cfg1_params(meta) -> Params:
     return Params.reference_defaults(horizon=meta["N"], dt=meta["dt"], max_velocity=meta["max_velocity"],
                                      max_acceleration=meta["max_acceleration"], max_iterations=meta["maxiter"], pgtol=meta["tol"],
@@ -505,6 +537,13 @@ def check_solver_extraction(h: Harness, N: int, B: int, seed: int = 3):
     ref0 = orc.straight_line_init(p0.astype(h.dt).astype(float), v0.astype(h.dt).astype(float),
                                   goal.astype(h.dt).astype(float), cfg)
     vec_close(h.to_host(out2["x"]).astype(float), np.clip(ref0, b[:, 0], b[:, 1]), 10 * h.tol["vec_rel"], "cold start")
+
+
+def mismatch_budget(B: int, dt) -> float:
+    """Fraction of a batch whose (nit, nfev, status) may differ from SciPy's: none in float64; in float32 0.2 % (measured on MI355X:
+    0.03 % over 340 000 + 126 000 random problems), i.e. at most one problem in batches below 500.  Whatever
+    differs is still held to check_solver_vs_oracle's unconditional rule (SciPy's point, or an objective no worse)."""
+    return 0.0 if np.dtype(dt) == np.float64 else max(0.002, 1.0 / B)
 
 
 def check_solver_vs_oracle(h: Harness, N: int, B: int, seed: int = 11, group=None, **overrides):

@@ -14,7 +14,7 @@ import build_emu  # noqa: E402
 from numpy_backend import NumpyBackend  # noqa: E402
 
 from dart_planner_amd import capi  # noqa: E402
-from dart_planner_amd.ops import Ops  # noqa: E402
+from dart_planner_amd.ops import Ops, INFO_DTYPE  # noqa: E402
 import parity_checks as pc  # noqa: E402
 
 
@@ -102,6 +102,13 @@ def test_solver_group_sizes(emu_ops, golden_solve, group):
     if group <= 16:
         worst, mism = pc.check_solver_vs_oracle(harness(emu_ops, np.float32), N, B, seed=group + 1, group=group)
         assert mism <= 0.1 and worst <= 1e-4
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_on_the_knife_edge_problem(emu_ops, dt):
+    for group in (None, 64):
+        branch, err = pc.check_solver_bifurcation_case(harness(emu_ops, dt), group=group)
+        print(f"knife-edge problem, {np.dtype(dt).name}, group {group}: {branch}, {err:.2e} m")
 
 
 def test_solver_extraction_and_cold_start(emu_ops):
@@ -279,3 +286,38 @@ def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
     assert ls("control_plan", "f64", cp, 2, p(t), p(t), p(z3), p(z3), p(z3), p(z3), 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(state), p(th), p(tq), 0, 0, 0, 0, 0) == 0
     assert ls("control_plan", "f64", cp, 2, p(t), 0, p(z3), p(z3), p(z3), p(z3), 2, p(ts), 0, p(P), 0, 0, 0, 0, 0, p(state), p(th), p(tq), 0, 0, 0, 0, 0) == -1
     assert lib._dll.se3mpc_set_solver_variant(2) == -3 and lib._dll.se3mpc_set_solver_variant(24 << 8) == -3 and lib._dll.se3mpc_set_solver_variant(0) == 0
+
+
+def test_plan_host_entry_point(emu_ops):
+    """se3mpc_plan_host_*: launch + completion ticket in one call.  Same numbers as se3mpc_solve_* on the same buffers; the ticket lands in
+    the completion word; a batch that needs more than one wavefront, a NULL completion word and a stale ticket are refused."""
+    import ctypes as C
+    lib = emu_ops.lib
+    for suf, dt in (("f32", np.float32), ("f64", np.float64)):
+        for N, B in ((6, 1), (6, 8), (30, 2), (40, 1)):
+            prm = capi.Params.reference_defaults(horizon=N)
+            rng = np.random.default_rng(N + B)
+            p0, v0, goal = (rng.uniform(-5, 5, (B, 3)).astype(dt) for _ in range(3))
+            outs = []
+            for mode in ("solve", "plan_host"):
+                X = np.zeros((B, 9 * N), dt); info = np.zeros((B,), INFO_DTYPE)
+                acc, att, rates = (np.zeros((B, N, 3), dt) for _ in range(3)); thr = np.zeros((B, N), dt)
+                ptr = lambda a: a.ctypes.data
+                args = [B, ptr(p0), ptr(v0), ptr(goal), 0, ptr(X), ptr(info), ptr(acc), ptr(att), ptr(rates), ptr(thr)]
+                if mode == "solve":
+                    lib.call("solve", suf, *args, None, params=prm)
+                else:
+                    done = np.zeros(1, np.uint64)
+                    lib.call("plan_host", suf, *args, ptr(done), 7, 1e6, None, params=prm)
+                    assert int(done[0]) == 7
+                    assert lib.call_status("plan_host", suf, *args, ptr(done), 7, 1e6, None, params=prm) == -3      # stale ticket
+                    assert lib.call_status("plan_host", suf, *args, 0, 8, 1e6, None, params=prm) == -1               # no completion word
+                outs.append((X, info, acc, att, rates, thr))
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b)
+    # more than one wavefront's worth of problems
+    prm = capi.Params.reference_defaults(horizon=30)
+    B = 3
+    z = np.zeros((B, 3), np.float32); X = np.zeros((B, 270), np.float32); info = np.zeros((B,), INFO_DTYPE); done = np.zeros(1, np.uint64)
+    assert lib.call_status("plan_host", "f32", B, z.ctypes.data, z.ctypes.data, z.ctypes.data, 0, X.ctypes.data, info.ctypes.data, 0, 0, 0, 0,
+                           done.ctypes.data, 1, 1e6, None, params=prm) == -3

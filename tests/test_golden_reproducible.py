@@ -15,6 +15,7 @@ pytestmark = pytest.mark.skipif(not os.path.isdir("/root/reference/src/dart_plan
 
 @pytest.mark.parametrize("script,files", [
     ("make_golden_cfg1.py", ["cfg1_solves.npz", "cfg1_solves.json"]),
+    ("make_golden_bifurcation.py", ["bifurcation_case.npz", "bifurcation_case.json"]),
     ("make_golden_controller.py", ["controller_cases.npz", "controller_cases.json"]),
     ("make_golden.py", ["solve_cases.npz", "solve_cases.json", "path_functions.npz", "path_functions.json", "mapper_spheres.npz", "mapper_spheres.json"]),
 ])

@@ -31,7 +31,7 @@ def harness(ops, dt):
 
 
 @pytest.mark.parametrize("dt", [np.float64, np.float32])
-@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (20, 257), (30, 1000), (50, 129), (64, 65), (7, 9), (33, 200), (24, 130), (17, 64), (32, 100)])
+@pytest.mark.parametrize("N,B", [(1, 5), (6, 70), (20, 257), (30, 1000), (30, 1024), (50, 129), (64, 65), (7, 9), (33, 200), (24, 130), (17, 64), (32, 100)])
 def test_lane_kernels(gpu_ops, dt, N, B):
     pc.check_lane_kernels(harness(gpu_ops, dt), N, B, seed=N, variants=(0, 1, 2, 3, 4, 5, 6))
 
@@ -112,7 +112,7 @@ def test_solver_published_cauchy_search(gpu_ops, golden_solve, golden_cfg1, dt):
         assert worst <= (1e-4 if dt == np.float32 else 1e-9)
         pc.check_solver_cfg1(harness(gpu_ops, dt), *golden_cfg1)
         w, mism = pc.check_solver_vs_oracle(harness(gpu_ops, dt), 30, 128, seed=2)
-        assert w <= (1e-4 if dt == np.float32 else 1e-9) and mism <= (0.0 if dt == np.float64 else 0.02)
+        assert w <= (1e-4 if dt == np.float32 else 1e-9) and mism <= pc.mismatch_budget(128, dt)
     finally:
         gpu_ops.lib.set_solver_variant(0)
 
@@ -157,7 +157,7 @@ def test_batched_solve_matches_scipy_problem_by_problem(gpu_ops, N, B):
         worst, mismatch = pc.check_solver_vs_oracle(harness(gpu_ops, dt), N, B, seed=N)
         print(f"N={N} B={B} {np.dtype(dt).name}: max position error {worst:.3e} m, iteration-count mismatches {mismatch:.4f}")
         assert worst <= tol
-        assert mismatch <= (0.0 if dt == np.float64 else 0.02)
+        assert mismatch <= pc.mismatch_budget(B, dt)
 
 
 @pytest.mark.parametrize("N,B", [(20, 64), (30, 96), (50, 64), (64, 48)])
@@ -168,9 +168,32 @@ def test_batched_solve_published_cauchy_search_matches_scipy(gpu_ops, N, B):
     try:
         for dt, tol in ((np.float64, 1e-9), (np.float32, 1e-4)):
             worst, mismatch = pc.check_solver_vs_oracle(harness(gpu_ops, dt), N, B, seed=100 + N)
-            assert worst <= tol and mismatch <= (0.0 if dt == np.float64 else 0.02), (N, np.dtype(dt).name, worst, mismatch)
+            assert worst <= tol and mismatch <= pc.mismatch_budget(B, dt), (N, np.dtype(dt).name, worst, mismatch)
     finally:
         gpu_ops.lib.set_solver_variant(0)
+
+
+@pytest.mark.parametrize("group", [8, 16, 32, 64])
+def test_solver_group_sizes(gpu_ops, golden_solve, group):
+    """The packed solver at every lanes-per-problem: golden solves whose horizon fits the group, and batches of random problems (several
+    wavefronts of 64 / group co-resident problems with different iteration counts, a ragged last one) against SciPy one by one."""
+    data, meta = golden_solve
+    keys = {c["key"] for c in meta["cases"] if c["N"] <= group}
+    for dt, tol in ((np.float64, 1e-9), (np.float32, 1e-4)):
+        assert pc.check_solver_golden(harness(gpu_ops, dt), data, meta, keys=keys, group=group) <= tol
+        for N in {8: (6, 8, 3), 16: (13, 16, 6), 32: (30, 20, 6), 64: (40, 64, 30)}[group]:
+            B = 5 * (64 // group) + 3
+            worst, mism = pc.check_solver_vs_oracle(harness(gpu_ops, dt), N, B, seed=group + N, group=group)
+            assert worst <= tol and mism <= pc.mismatch_budget(B, dt), (group, N, np.dtype(dt).name, worst, mism)
+
+
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_solver_on_the_knife_edge_problem(gpu_ops, dt):
+    """tests/golden/bifurcation_case: the fuzz sweeps' one 0.376 m "mismatch" -- a problem on which the last bit of an objective value
+    picks between two outcomes.  The result must be one of the two (the reference's own, or the other branch); printed: which."""
+    for group in (None, 64):
+        branch, err = pc.check_solver_bifurcation_case(harness(gpu_ops, dt), group=group)
+        print(f"knife-edge problem, {np.dtype(dt).name}, group {group}: {branch}, {err:.2e} m")
 
 
 def test_batched_solve_tight_tolerances(gpu_ops):
@@ -372,7 +395,7 @@ def test_monte_carlo_full_size(gpu_ops):
     o64 = ops.solve(prm, d(rep(p0[sub])), d(rep(v0[sub])), d(rep(goal[sub])), x0=d(X0[sub].reshape(-1, 9 * N)), want_trajectory=False)
     i64 = ops.info_to_host(o64["info"])
     same = (i64["nit"] == info[sub].reshape(-1)["nit"]) & (i64["nfev"] == info[sub].reshape(-1)["nfev"])
-    assert same.mean() >= 0.98
+    assert same.mean() >= 1 - pc.mismatch_budget(len(same), np.float32)
     err = (o64["x"] - x[sub].reshape(-1, 9 * N).double()).abs()[torch.from_numpy(same).to(dev)][:, :3 * N].max()
     assert float(err) <= 1e-4
     # 512 PERTURBED restarts (never restart 0) against SciPy from the same x0, problem by problem: the f64 solve must
@@ -395,11 +418,15 @@ def test_monte_carlo_full_size(gpu_ops):
         xr, ir = orc.solve(hp0[j], hv0[j], hg[j], cfg, x0=hx0[j])
         assert (int(i64["nit"][j]), int(i64["nfev"][j]), int(i64["status"][j])) == (ir["nit"], ir["nfev"], ir["status"]), j
         worst64 = max(worst64, float(np.max(np.abs(x64[j, :3 * N] - xr[:3 * N]))))
+        e32 = float(np.max(np.abs(x32[j, :3 * N] - xr[:3 * N])))
         if (int(i32["nit"][j]), int(i32["nfev"][j]), int(i32["status"][j])) == (ir["nit"], ir["nfev"], ir["status"]):
             same32 += 1
-            worst32 = max(worst32, float(np.max(np.abs(x32[j, :3 * N] - xr[:3 * N]))))
+            worst32 = max(worst32, e32)
+        elif e32 > 1e-4:
+            # unconditional: a float32 solve that counts differently must still end at SciPy's point or at an objective no worse
+            assert float(i32["fun"][j]) <= ir["fun"] * (1 + 1e-6) + 1e-12, (j, e32, float(i32["fun"][j]), ir["fun"])
     print(f"config 5, 512 perturbed restarts vs SciPy: f64 {worst64:.2e} m, f32 {worst32:.2e} m ({same32}/512 on SciPy's path)")
-    assert worst64 <= 1e-9 and worst32 <= 1e-4 and same32 >= 0.98 * 512
+    assert worst64 <= 1e-9 and worst32 <= 1e-4 and same32 >= (1 - pc.mismatch_budget(512, np.float32)) * 512
 
 
 def test_wave_ops_selftest(gpu_ops):

@@ -1,10 +1,14 @@
 """The oracle (oracle/se3mpc_oracle.py) against vectors produced by the reference itself
 (tests/golden/make_golden.py) and the SURVEY.md Appendix-B known answer.  CPU only."""
+import os
+
 import numpy as np
 import pytest
 
 from oracle import se3mpc_oracle as orc
 from oracle.se3mpc_oracle import OracleConfig
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 TOL = dict(rtol=1e-12, atol=1e-10)
 
@@ -145,3 +149,28 @@ def test_oracle_reproduces_config1_solves(golden_cfg1):
         ex = orc.extract_solution(x, cfg)
         for name in ("accelerations", "attitudes", "body_rates", "thrusts"):
             assert np.max(np.abs(ex[name] - data[name][i])) <= 1e-9, name
+
+
+def test_objective_ordered_rounds_like_the_reference_loops():
+    """oracle.objective_ordered (what solve() hands SciPy) == the reference-shaped per-step loops, BIT FOR BIT."""
+    rng = np.random.default_rng(0)
+    for N in (1, 2, 6, 7, 20, 30, 50, 64):
+        cfg = orc.OracleConfig(prediction_horizon=N)
+        for t in range(60):
+            x = rng.normal(0, 5, 9 * N)
+            goal = rng.uniform(-20, 20, 3) if t % 5 else None
+            assert orc.objective_ordered(x, goal, cfg) == orc.objective_loops(x, goal, cfg)
+
+
+def test_oracle_reproduces_the_reference_on_the_knife_edge_problem():
+    """tests/golden/bifurcation_case: the reference ends at (3, 27), f = 2680.18; SciPy on a batched-sum objective at (3, 24), f = 2728.05,
+    0.376 m away.  The oracle's solve() (reference-ordered objective) must be on the reference's side, exactly."""
+    import json
+    data = np.load(os.path.join(GOLDEN, "bifurcation_case.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "bifurcation_case.json")))
+    cfg = orc.OracleConfig(prediction_horizon=meta["N"], dt=meta["dt"], **meta["weights"])
+    x, info = orc.solve(data["p0"], data["v0"], data["goal"], cfg)
+    ref = meta["reference"]
+    assert (info["nit"], info["nfev"], info["status"]) == (ref["nit"], ref["nfev"], ref["status"])
+    assert np.max(np.abs(x - data["x_reference"])) <= 1e-12 and abs(info["fun"] - ref["fun"]) <= 1e-9
+    assert meta["gap_m"] > 0.3 and meta["other_branch"]["nfev"] == 24

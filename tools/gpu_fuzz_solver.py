@@ -42,11 +42,13 @@ def sweep(h, N, B, seed, **ov):
             worst_same = max(worst_same, err)
         else:
             worst_diff = max(worst_diff, err)
-            mism.append(dict(problem=i, kernel=got, scipy=(ir["nit"], ir["nfev"], ir["status"]), position_error_m=err))
+            mism.append(dict(problem=i, seed=seed, kernel=got, scipy=(ir["nit"], ir["nfev"], ir["status"]), position_error_m=err,
+                             kernel_fun=float(info["fun"][i]), scipy_fun=ir["fun"]))
     return worst_same, worst_diff, mism
 
 
-tot = dict(problems=0, count_mismatches=0, worst_f64=0.0, worst_f32=0.0, worst_on_count_mismatch=0.0)
+tot = dict(problems=0, count_mismatches=0, worst_f64=0.0, worst_f32=0.0, worst_on_count_mismatch=0.0, worst_mismatched_problem=None,
+           mismatched_ending_worse_than_scipy=0)
 t0 = time.time()
 # the published sequential Cauchy search (se3mpc_set_solver_variant(1)) at the three register-slot counts (J = 3, 6, 9)
 configs += [(N, dict(_solver_variant=1)) for N in (20, 30, 50, 64)]
@@ -61,8 +63,15 @@ for i, (N, ov) in enumerate(configs):
             ops.lib.set_solver_variant(0)
         ov_print = dict(ov, solver_variant=variant) if variant else ov
         tot["problems"] += B; tot["count_mismatches"] += len(mism); tot[key] = max(tot[key], ws)
+        for mm in mism:
+            # the unconditional parity rule of tests/parity_checks.check_solver_vs_oracle: another path may not end somewhere worse
+            if mm["position_error_m"] > (1e-4 if dt == np.float32 else 1e-9) and mm["kernel_fun"] > mm["scipy_fun"] * (1 + 1e-6) + 1e-12:
+                tot["mismatched_ending_worse_than_scipy"] += 1
+            if mm["position_error_m"] >= tot["worst_on_count_mismatch"]:
+                tot["worst_mismatched_problem"] = dict(mm, horizon=N, options=ov_print, dtype=np.dtype(dt).name)
         tot["worst_on_count_mismatch"] = max(tot["worst_on_count_mismatch"], wd)
+        # EVERY mismatched problem is in the record (index + seed regenerate it: tests/parity_checks.random_batch)
         print(json.dumps(dict(horizon=N, options=ov_print, dtype=np.dtype(dt).name, problems=B, iteration_count_mismatches=len(mism),
-                              max_position_error_m=ws, mismatched=mism[:8])), flush=True)
+                              max_position_error_m=ws, max_position_error_on_count_mismatch_m=wd, mismatched=mism)), flush=True)
 tot["seconds"] = round(time.time() - t0, 1)
 print(json.dumps(tot))
