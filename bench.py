@@ -323,8 +323,10 @@ def main():
     if a.dry_run:
         return dry_run(a, rank, world)
     cpu_stats = None
-    if world == 1 and not a.no_cpu_baseline:
-        cpu_stats = cpu_baseline(a.batch, a.horizon, a.cpu_seconds)      # before any HIP call: it spawns worker processes
+    if rank == 0 and not a.no_cpu_baseline:
+        # rank 0 only, also when several ranks run (the other ranks wait for it at the rendezvous, outside every timed region);
+        # before any HIP call: it spawns worker processes
+        cpu_stats = cpu_baseline(a.batch, a.horizon, a.cpu_seconds)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
     ndev = torch.cuda.device_count()
@@ -726,6 +728,33 @@ def iterated_leg(torch, ops, dev, B, N, min_ms, ks=(0, 1, 4, 16, 64)):
         del graph
         out["batched_64_K16"] = {"launch_us": us, "rollouts_per_launch": B * S * (K + 1), "rollouts_per_s": B * S * (K + 1) / (us * 1e-6),
                                  "us_per_iteration_per_batch": us / S / (K + 1), "hbm_GB_per_s": (4 * (9 + 3 * N) + 4 * (1 + 6 * N)) * B * S / (us * 1e-6) / 1e9}
+    # BASELINE config 3 INSIDE the loop (se3mpc_rollout_iterate_obstacles_*: running cost + obstacle penalty, the build's extension):
+    # horizon 50, 8192 trajectories, 16 mapper-style spheres (radius 1.0, 0.5 m grid, margin 1.5), one launch per K
+    N3, K3 = 50, 16
+    prm3 = Params.reference_defaults(horizon=N3)
+    slot3 = 4 * B * ((9 + 3 * N3) + (1 + 6 * N3))
+    ring3 = max(32, math.ceil(320 * 2 ** 20 / slot3))
+    q0, w0, gl3, T3, cost3, grad3 = make_ring(torch, dev, B, N3, ring3, seed=78)
+    q0.mul_(0.1); gl3.mul_(0.1)
+    Tout3 = torch.empty_like(T3)
+    gs = torch.Generator(device="cpu"); gs.manual_seed(2)
+    sph = torch.cat([torch.round(torch.rand(K3, 3, generator=gs) * 30) / 2 - 3.75, torch.ones(K3, 1)], dim=1).to(dev)
+    rows, base3 = [], None
+    for K in (0, 1, 4, 16):
+        nl = min(ring3, 64)
+        body = lambda: [ops.rollout_iterate(prm3, q0[i], w0[i], gl3[i], T3[i], K, 1e-3, out=(Tout3[i], cost3[i], grad3[i]), spheres=sph,
+                                            obstacle_weight=1000.0, want_penalty=False) for i in range(nl)]
+        body(); torch.cuda.synchronize()
+        graph = capture(torch, dev, body)
+        ms1 = device_ms(torch, graph.replay, 2)
+        us = device_ms(torch, graph.replay, max(2, math.ceil(min_ms / max(ms1, 1e-6)))) / nl * 1e3
+        del graph
+        base3 = us if K == 0 else base3
+        rows.append({"K": K, "launch_us": us, "us_per_iteration": None if K == 0 else (us - base3) / K, "rollouts_per_s": B * (K + 1) / (us * 1e-6),
+                     "distance_evaluations_per_s": B * (K + 1) * N3 * K3 / (us * 1e-6)})
+    out["cfg3_obstacles"] = {"what": f"horizon={N3}, batch={B}, {K3} spheres: K obstacle-aware iterations + a final evaluation per launch "
+                                     f"({N3 * K3} distance evaluations per trajectory and pass; thrusts, states and obstacle gradients stay on chip)",
+                             "per_K": rows}
     out["note"] = ("rollout_equivalent_GB_per_s prices every in-register rollout at the 4*(6N+10) B a stand-alone launch would move; it may "
                    "exceed the HBM peak -- the iterations in between touch no memory -- and is NOT a roofline fraction; the bound of this "
                    "kernel is the dependent-instruction latency of the 2N-step sweep per iteration")

@@ -131,8 +131,9 @@ class GeometricController:
     def _state_args(self, current_state: DroneState):
         z = np.zeros(3)
         att = np.asarray(to_float(current_state.attitude), float)
-        if att.shape[0] == 4:                                # quaternion attitude (controller.py:791-803): to Euler angles once
-            w, x, y, zq = att
+        if att.shape[0] == 4:                                # quaternion attitude (controller.py:785-803): normalised (identity below 1e-6), to Euler angles once
+            nq = float(np.sqrt(att @ att))
+            w, x, y, zq = (att / nq) if nq > 1e-6 else np.array([1.0, 0.0, 0.0, 0.0])
             att = np.array([np.arctan2(2 * (w * x + y * zq), 1 - 2 * (x * x + y * y)), np.arcsin(np.clip(2 * (w * y - zq * x), -1, 1)),
                             np.arctan2(2 * (w * zq + x * y), 1 - 2 * (y * y + zq * zq))])
         row = lambda a: self._dev(np.asarray(to_float(a), float).reshape(1, 3))
@@ -338,9 +339,13 @@ class GeometricController:
     def unsaturated_torque(self, v) -> None:
         self._set_words(6, np.asarray(v, float).reshape(3))
 
-    def reset(self) -> None:                                 # controller.py:840-860
+    def reset(self) -> None:                                 # controller.py:853-869
         if self._state is not None:
+            # the reference's reset() does not undo the gain halving its failsafe did IN PLACE on self.config (controller.py:817-821): the
+            # count of halvings (word 10 of the record, from which the kernels derive the gains) survives a reset
+            halvings = self._word(10)
             self._get_ops().lib.controller_reset(self._params(), 1, self._state.data_ptr(), self._get_ops().be.stream())
+            self._set_words(10, [halvings])
         self.position_errors, self.velocity_errors, self.control_outputs = [], [], []
         self._thrust_saturation_count = self._torque_saturation_count = 0
 

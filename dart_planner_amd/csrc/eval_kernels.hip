@@ -739,11 +739,83 @@ __device__ __forceinline__ R projected_update(R t, R g, R step, R lo, R hi) {
   return fmin(fmax(fma_r(-step, g, t), lo), hi);
 }
 
-template <typename R, int N, bool EXACT, int LDAUX, int STAUX>
+// ---- obstacle-aware iterations (BASELINE config 3 inside the iteration loop) ---------------------------------------------
+// The build's EXTENSION of the shooting objective (the reference builds the sphere residuals c_kj = |P_k - c_j|^2 - (r_j + margin)^2,
+// planner.py:499-514, and never hands them to its solver, :250 vs :256-268; its obstacle_weight, :63, is never read):
+//     penalty = w_obs * sum_k sum_j max(0, -c_kj)^2          on the rolled-out positions,
+// whose gradient wrt P_k, -4 w_obs sum_j max(0, -c_kj) (P_k - c_j), joins the adjoint of the position in the reverse sweep.
+// The penalty couples the three axes, so an iteration becomes: axis wavefronts roll out and stage P_k in the LDS tile
+// [axis][k][lane] -> barrier -> ALL W wavefronts of the workgroup split the steps (k = w, w + W, ...), evaluate the N*K
+// distances against the LDS-resident sphere table and overwrite P_k IN PLACE with dpenalty/dP_k -> barrier -> axis wavefronts
+// run the adjoint sweep reading their component back.  Thrusts, states and the per-step obstacle gradients never touch HBM.
+template <typename R>
+struct ObsCtx {
+  R* tile;            // [3][N][64]
+  const R* sph;       // [Kpad][4] = (cx, cy, cz, (r + margin)^2), padding rows -inf
+  R* pen;             // [W][64]: each wavefront's share of the penalty, last pass
+  R* pen_first;       // [W][64]: the same at the first pass (cost at T_in)
+  int Kpad, W;
+  R w_obs;
+};
+
+// steps k = w, w + W, ... of every lane's trajectory: tile holds P_k on entry and dpenalty/dP_k on exit; returns this wavefront's
+// share of the penalty (already weighted)
+template <typename R>
+__device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int w, int W, int lane,
+                                                    R w_obs) {
+  R pen = (R)0;
+  const R scale = (R)-4 * w_obs;
+  for (int k = w; k < Nn; k += W) {
+    R* tx = tile + ((size_t)0 * Nn + k) * kWave + lane;
+    R* ty = tile + ((size_t)1 * Nn + k) * kWave + lane;
+    R* tz = tile + ((size_t)2 * Nn + k) * kWave + lane;
+    const R px = *tx, py = *ty, pz = *tz;
+    if constexpr (sizeof(R) == 4) {
+      typedef float f2 __attribute__((vector_size(8)));
+      const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz}, zero = {0.0f, 0.0f};
+      f2 qx = zero, qy = zero, qz = zero, pk = zero;
+#pragma unroll 4
+      for (int j = 0; j < Kpad; j += 2) {                      // two spheres per packed instruction (Kpad is a multiple of 8)
+        const R* s0 = sph + 4 * j;
+        const f2 dx = px2 - f2{s0[0], s0[4]}, dy = py2 - f2{s0[1], s0[5]}, dz = pz2 - f2{s0[2], s0[6]};
+        const f2 c = (dx * dx + dy * dy + dz * dz) - f2{s0[3], s0[7]};
+        const f2 h = f2{fmaxf(0.0f, -c[0]), fmaxf(0.0f, -c[1])};
+        pk += h * h; qx += h * dx; qy += h * dy; qz += h * dz;
+      }
+      pen += pk[0] + pk[1];
+      *tx = scale * (qx[0] + qx[1]); *ty = scale * (qy[0] + qy[1]); *tz = scale * (qz[0] + qz[1]);
+    } else {
+      R qx = (R)0, qy = (R)0, qz = (R)0, pk = (R)0;
+      for (int j = 0; j < Kpad; ++j) {
+        const R* s0 = sph + 4 * j;
+        const R dx = px - s0[0], dy = py - s0[1], dz = pz - s0[2];
+        const R c = (dx * dx + dy * dy + dz * dz) - s0[3];
+        const R h = fmax((R)0, -c);
+        pk += h * h; qx += h * dx; qy += h * dy; qz += h * dz;
+      }
+      pen += pk;
+      *tx = scale * qx; *ty = scale * qy; *tz = scale * qz;
+    }
+  }
+  return w_obs * pen;
+}
+
+// one exchange of an obstacle-aware pass, executed by EVERY wavefront of the workgroup (axis wavefronts from inside their sweeps,
+// the helper wavefronts from the kernel body): barrier, this wavefront's share of the sweep, barrier
+template <typename R>
+__device__ __forceinline__ void obstacle_exchange(const ObsCtx<R>& o, int Nn, int w, int lane, bool first) {
+  __syncthreads();
+  const R pen = obstacle_penalty_sweep<R>(o.tile, o.sph, Nn, o.Kpad, w, o.W, lane, o.w_obs);
+  o.pen[w * kWave + lane] = pen;
+  if (first) o.pen_first[w * kWave + lane] = pen;
+  __syncthreads();
+}
+
+template <typename R, int N, bool EXACT, int LDAUX, int STAUX, bool OBS = false>
 __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
                                               R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, bool want_first,
-                                              R& cost_first) {
+                                              R& cost_first, const ObsCtx<R>* obs = nullptr) {
   // `live`: tail lanes shadow the last trajectory (identical loads) but must not store -- Tout may alias Tin.
   // The sweeps come in two flavours so that the iterations in between carry no dead weight: the descent iterations roll out the
   // states only (no cost sums) and consume the gradient in place; cost sums and gradient stores exist only in the evaluation
@@ -758,6 +830,9 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
   const R pinit = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
   const R vinit = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
   const R lo = (a == 2) ? q.tz_lo : -q.txy, hi = (a == 2) ? q.tz_hi : q.txy;      // planner.py:390-400
+  const int lane_ = (int)(threadIdx.x & (kWave - 1));
+  R* my_tile = nullptr;                                       // OBS: this axis' column of the position / obstacle-gradient tile
+  if constexpr (OBS) my_tile = obs->tile + (size_t)a * Nn * kWave + lane_;
   // forward sweep with the cost sums (evaluation passes)
   auto forward_cost = [&]() -> R {
     R p = pinit, v = vinit;
@@ -769,6 +844,7 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
         const R dev = t[k] - c.hov;
         const R e = p - c.gl;
         es[k] = e; vs[k] = v;
+        if constexpr (OBS) my_tile[(size_t)k * kWave] = p;
         if (k == Nn - 1) s.sterm = e * e; else s.sp += e * e;
         s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
         p = p + v * q.dt + q.half_dt2 * acc;
@@ -779,7 +855,11 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
     return axis_cost(q, s);
   };
   cost_first = (R)0;
-  if (want_first && iters > 0) cost_first = forward_cost();
+  bool first_exchange = true;
+  if (want_first && iters > 0) {
+    cost_first = forward_cost();
+    if constexpr (OBS) { obstacle_exchange<R>(*obs, Nn, a, lane_, first_exchange); first_exchange = false; }     // the penalty at T_in
+  }
   // Descent iterations in their leanest algebraically equal form (11 VALU per step instead of 17): the position error e = P - goal is
   // rolled out directly (the goal is constant, so e obeys P's recurrence), the local part of the gradient is one fma
   //   d/dT_k [wa acc^2 + wT (T - hover)^2] = gA T_k - gB,   gA = 2 wa / m^2 + 2 wT,  gB = 2 wa g / m + 2 wT hover,
@@ -797,22 +877,26 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
       if (EXACT || k < Nn) {
         const R acc = fma_r(t[k], q.inv_mass, -c.grav);
         es[k] = e; vs[k] = v;
+        if constexpr (OBS) my_tile[(size_t)k * kWave] = e + c.gl;
         e = fma_r(q.half_dt2, acc, fma_r(v, q.dt, e));
         v = fma_r(acc, q.dt, v);
       }
     }
+    if constexpr (OBS) { obstacle_exchange<R>(*obs, Nn, a, lane_, first_exchange); first_exchange = false; }
     R lamP = (R)0, lamV = (R)0;
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {                          // adjoint sweep; T_k is overwritten as soon as its gradient exists
       if (EXACT || k < Nn) {
+        R qk = (R)0;                                            // dpenalty/dP_k of this axis (OBS)
+        if constexpr (OBS) qk = my_tile[(size_t)k * kWave];
         if (k == Nn - 1) {
           t[k] = clamp_r(fma_r(t[k], u1, u0), lo, hi);
-          lamP = lamP_term * es[k];
+          if constexpr (OBS) lamP = fma_r(lamP_term, es[k], qk); else lamP = lamP_term * es[k];
           lamV = c.two_wv * vs[k];
         } else {
           t[k] = clamp_r(fma_r(t[k], u1, fma_r(lamP, uP, fma_r(lamV, uV, u0))), lo, hi);
           lamV = fma_r(c.two_wv, vs[k], fma_r(q.dt, lamP, lamV));
-          lamP = fma_r(c.two_wp, es[k], lamP);
+          if constexpr (OBS) lamP = fma_r(c.two_wp, es[k], lamP + qk); else lamP = fma_r(c.two_wp, es[k], lamP);
         }
       }
     }
@@ -820,6 +904,7 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
   // the last evaluation: cost and gradient at the final T (the gradient parks in the state registers it has just consumed)
   const R cost = forward_cost();
   if (!(want_first && iters > 0)) cost_first = cost;
+  if constexpr (OBS) obstacle_exchange<R>(*obs, Nn, a, lane_, first_exchange);
   if (gradT != nullptr) {
     R lamP = (R)0, lamV = (R)0;
 #pragma unroll
@@ -827,15 +912,18 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
       if (EXACT || k < Nn) {
         const R acc = t[k] * q.inv_mass - c.grav;
         const R dev = t[k] - c.hov;
+        R qk = (R)0;
+        if constexpr (OBS) qk = my_tile[(size_t)k * kWave];
         R g;
         if (k == Nn - 1) {
           g = c.c_aa * acc + c.c_tt * dev;
           lamP = c.two_wp * ((R)1 + q.term) * es[k];
+          if constexpr (OBS) lamP += qk;
           lamV = c.two_wv * vs[k];
         } else {
           g = c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV;
           lamV = c.two_wv * vs[k] + q.dt * lamP + lamV;
-          lamP = c.two_wp * es[k] + lamP;
+          if constexpr (OBS) lamP = c.two_wp * es[k] + (lamP + qk); else lamP = c.two_wp * es[k] + lamP;
         }
         es[k] = g;
       }
@@ -858,20 +946,28 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
 
 // Any horizon: the working copy of T lives in Tout (the lane's own elements, L1/L2-resident between iterations); states are
 // recovered by walking the recurrence backwards as in rollout_axis_rev.
-template <typename R>
+template <typename R, bool OBS = false>
 __device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
                                               R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, bool want_first,
-                                              R& cost_first) {
+                                              R& cost_first, const ObsCtx<R>* obs = nullptr) {
   (void)want_first;
-  // the working copy lives in Tout, so a tail lane has nothing of its own to iterate on: it leaves (no cross-lane op below)
-  if (!live) { cost_first = (R)0; return (R)0; }
   const int N = q.N;
+  const int lane_ = (int)(threadIdx.x & (kWave - 1));
+  // the working copy lives in Tout, so a tail lane has nothing of its own to iterate on: it leaves (no cross-lane op below).  Not so in
+  // the obstacle-aware form, whose passes meet at workgroup barriers: a barrier is an instruction of the WAVEFRONT, so tail lanes
+  // must walk the same code as their wavefront's live lanes (a second copy of the loop in a divergent branch would make the wavefront
+  // execute every barrier twice); there they compute on zeros and neither load nor store.
+  if constexpr (!OBS) {
+    if (!live) { cost_first = (R)0; return (R)0; }
+  }
+  R* my_tile = nullptr;
+  if constexpr (OBS) my_tile = obs->tile + (size_t)a * N * kWave + lane_;
   const AxisConsts<R> c = axis_consts<R>(q, a, q.has_goal ? lane_ld(lane_buf(goal), voff, (unsigned)(a) * rowb) : (R)0);
   const R pinit = lane_ld(lane_buf(p0), voff, (unsigned)(a) * rowb);
   const R vinit = lane_ld(lane_buf(v0), voff, (unsigned)(a) * rowb);
   const R lo = (a == 2) ? q.tz_lo : -q.txy, hi = (a == 2) ? q.tz_hi : q.txy;
-  if (Tin != Tout) {
+  if (Tin != Tout && live) {
     for (int k = 0; k < N; ++k) lane_st(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, lane_ld(lane_buf(Tin), voff, (unsigned)(3 * k + a) * rowb));
   }
   R cost = (R)0;
@@ -882,12 +978,13 @@ __device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsi
     RolloutSums<R> s = {0, 0, 0, 0, 0};
 #pragma unroll 6
     for (int k = 0; k < N; ++k) {
-      tk = lane_ld(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb);
+      tk = (!OBS || live) ? lane_ld(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb) : (R)0;
       const R acc = tk * q.inv_mass - c.grav;
       const R dev = tk - c.hov;
       const R e = p - c.gl;
       if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
       s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      if constexpr (OBS) my_tile[(size_t)k * kWave] = p;
       pl = p; vl = v;
       p = p + v * q.dt + q.half_dt2 * acc;
       v = v + acc * q.dt;
@@ -895,26 +992,32 @@ __device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsi
     s.sp += s.sterm;
     cost = axis_cost(q, s);
     if (it == 0) cost_first = cost;
+    if constexpr (OBS) obstacle_exchange<R>(*obs, N, a, lane_, it == 0);
     R lamP = c.two_wp * ((R)1 + q.term) * (pl - c.gl);
+    if constexpr (OBS) lamP += my_tile[(size_t)(N - 1) * kWave];
     R lamV = c.two_wv * vl;
     {
       const R g = c.c_aa * (tk * q.inv_mass - c.grav) + c.c_tt * (tk - c.hov);
-      if (last) { if (gradT != nullptr) lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, g); }
-      else lane_st(lane_buf(Tout), voff, (unsigned)(3 * (N - 1) + a) * rowb, projected_update(tk, g, step, lo, hi));
+      if (!OBS || live) {
+        if (last) { if (gradT != nullptr) lane_st(lane_buf(gradT), voff, (unsigned)(3 * (N - 1) + a) * rowb, g); }
+        else lane_st(lane_buf(Tout), voff, (unsigned)(3 * (N - 1) + a) * rowb, projected_update(tk, g, step, lo, hi));
+      }
     }
     R pk = pl, vk = vl;
 #pragma unroll 6
     for (int k = N - 2; k >= 0; --k) {
-      const R tt = lane_ld(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb);
+      const R tt = (!OBS || live) ? lane_ld(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb) : (R)0;
       const R acc = tt * q.inv_mass - c.grav;
       const R dev = tt - c.hov;
       vk = vk - acc * q.dt;
       pk = pk - vk * q.dt - q.half_dt2 * acc;
       const R g = c.c_aa * acc + c.c_tt * dev + c.c_lp * lamP + c.c_lv * lamV;
-      if (last) { if (gradT != nullptr) lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, g); }
-      else lane_st(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, projected_update(tt, g, step, lo, hi));
+      if (!OBS || live) {
+        if (last) { if (gradT != nullptr) lane_st(lane_buf(gradT), voff, (unsigned)(3 * k + a) * rowb, g); }
+        else lane_st(lane_buf(Tout), voff, (unsigned)(3 * k + a) * rowb, projected_update(tt, g, step, lo, hi));
+      }
       lamV = c.two_wv * vk + q.dt * lamP + lamV;
-      lamP = c.two_wp * (pk - c.gl) + lamP;
+      if constexpr (OBS) lamP = c.two_wp * (pk - c.gl) + (lamP + my_tile[(size_t)k * kWave]); else lamP = c.two_wp * (pk - c.gl) + lamP;
     }
   }
   return cost;
@@ -951,6 +1054,73 @@ rollout_iterate_kernel(DevParams<R> q, int B, int ld, int iters, R step, const R
   __syncthreads();
   const R total = part[0][0][lane] + part[0][1][lane] + part[0][2][lane];
   if (a == 0 && live && cost_first != nullptr) cost_first[b] = part[1][0][lane] + part[1][1][lane] + part[1][2][lane];
+  rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
+}
+
+// The obstacle-aware form of rollout_iterate_kernel (see ObsCtx above).  W wavefronts per workgroup: the three axis wavefronts, and
+// for W = 8 five helpers that only take their share of the distance evaluations (for batches that leave SIMDs idle the evaluations
+// are the critical path: 800 per trajectory and iteration at horizon 50 with 16 spheres against ~600 instructions of rollout).
+// cost = running cost + penalty at T_out; penalty: NULL or [B] = the penalty alone (0 = the plan keeps the margin of every sphere).
+template <typename R, int N, bool REG, int FLAGS, int W>
+__global__ void __launch_bounds__(64 * W)
+rollout_iterate_obstacles_kernel(DevParams<R> q, int B, int ld, int iters, R step, const R* __restrict__ p0, const R* __restrict__ v0,
+                                 const R* __restrict__ goal, const R* __restrict__ Tin, R* __restrict__ Tout, R* __restrict__ cost_first,
+                                 R* __restrict__ cost, R* __restrict__ gradT, const R* __restrict__ spheres, int K, R w_obs,
+                                 R* __restrict__ penalty, unsigned long long* __restrict__ key, uint32_t index_base) {
+  HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  {
+    const size_t bi = blockIdx.y, ss = (size_t)3 * ld, st = (size_t)3 * q.N * ld;
+    p0 += bi * ss; v0 += bi * ss; Tin += bi * st; Tout += bi * st; cost += bi * (size_t)ld;
+    if (goal != nullptr) goal += bi * ss;
+    if (gradT != nullptr) gradT += bi * st;
+    if (cost_first != nullptr) cost_first += bi * (size_t)ld;
+    if (penalty != nullptr) penalty += bi * (size_t)ld;
+    if (key != nullptr) key += bi * (size_t)gridDim.x;
+  }
+  const int Kpad = (K + 7) / 8 * 8;
+  R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]: positions, then dpenalty/dP, of the pass in flight
+  R* sph = tile + (size_t)3 * q.N * kWave;                   // [Kpad][4]
+  R* pcost = sph + (size_t)4 * Kpad;                         // [3][64] axis costs at T_out, [3][64] at T_in
+  R* ppen = pcost + 6 * kWave;                               // [W][64] penalty shares at T_out, [W][64] at T_in
+  for (int i = threadIdx.x; i < Kpad; i += 64 * W) {         // visible to every wavefront behind the first exchange's barrier
+    if (i < K) {
+      const R sm = spheres[4 * i + 3] + q.margin;
+      sph[4 * i + 0] = spheres[4 * i + 0]; sph[4 * i + 1] = spheres[4 * i + 1]; sph[4 * i + 2] = spheres[4 * i + 2]; sph[4 * i + 3] = sm * sm;
+    } else {
+      sph[4 * i + 0] = (R)0; sph[4 * i + 1] = (R)0; sph[4 * i + 2] = (R)0; sph[4 * i + 3] = (R)-INFINITY;
+    }
+  }
+  int blk = blockIdx.x;
+  if ((FLAGS & 4) && (gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
+  const int lane = threadIdx.x & (kWave - 1);
+  const int b0 = blk * kWave + lane;
+  const bool live = b0 < B;
+  const int b = live ? b0 : B - 1;
+  const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
+  const int a = wave_uniform((int)(threadIdx.x / kWave));
+  ObsCtx<R> o;
+  o.tile = tile; o.sph = sph; o.pen = ppen; o.pen_first = ppen + W * kWave; o.Kpad = Kpad; o.W = W; o.w_obs = w_obs;
+  if (a < 3) {
+    R c0 = (R)0, c;
+    if constexpr (REG) c = iterate_axis_reg<R, N, !(FLAGS & 8), (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0, true>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0, &o);
+    else c = iterate_axis_mem<R, true>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0, &o);
+    pcost[a * kWave + lane] = c; pcost[(3 + a) * kWave + lane] = c0;
+  } else {
+    // as many exchanges as the axis wavefronts run: one per descent iteration, the last evaluation, and (register form) the
+    // evaluation at T_in when its cost is asked for
+    const int passes = iters + 1 + ((REG && cost_first != nullptr && iters > 0) ? 1 : 0);
+    for (int ps = 0; ps < passes; ++ps) obstacle_exchange<R>(o, q.N, a, lane, ps == 0);
+  }
+  __syncthreads();
+  R total = pcost[0 * kWave + lane] + pcost[1 * kWave + lane] + pcost[2 * kWave + lane];
+  R pen = (R)0, pen0 = (R)0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) { pen += ppen[w * kWave + lane]; pen0 += ppen[(W + w) * kWave + lane]; }
+  total += pen;
+  if (a == 0 && live) {
+    if (cost_first != nullptr) cost_first[b] = pcost[3 * kWave + lane] + pcost[4 * kWave + lane] + pcost[5 * kWave + lane] + pen0;
+    if (penalty != nullptr) penalty[b] = pen;
+  }
   rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
 }
 
@@ -1775,6 +1945,56 @@ int rollout_iterate_impl(const se3mpc_params* p, int B, int ld, int nbatch, int 
 }
 
 template <typename R>
+int rollout_iterate_obstacles_impl(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const R* p0, const R* v0,
+                                   const R* goal, const R* Tin, R* Tout, R* cost_first, R* cost, R* gradT, const R* spheres, int K,
+                                   double obstacle_weight, R* penalty, uint64_t* key64, uint32_t index_base, void* stream) {
+  if (nbatch < 1 || nbatch > 65535 || iters < 0 || iters > 1000000 || K < 0 || K > SE3MPC_MAX_SPHERES) return SE3MPC_ERR_SHAPE;
+  int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));
+  if (rc) return rc;
+  if (!std::isfinite(step) || !std::isfinite(obstacle_weight) || obstacle_weight < 0.0) return SE3MPC_ERR_PARAM;
+  if (B == 0) return SE3MPC_OK;
+  if (!p0 || !v0 || !Tin || !Tout || !cost || (p->has_goal && !goal) || (K > 0 && !spheres)) return SE3MPC_ERR_NULL;
+  unsigned long long* key = reinterpret_cast<unsigned long long*>(key64);
+  const DevParams<R> q = make_dev_params<R>(*p);
+  const int N = p->horizon, nblk = grid_for(B, kWave);
+  hipStream_t s = (hipStream_t)stream;
+  const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
+  const bool has_bucket = sizeof(R) == 4 && N > 16 && N <= 32;
+  // eight wavefronts per workgroup while that still leaves SIMDs idle (1024 single-wave slots on the chip), three beyond
+  const int forced_w = (g_rollout_variant >> 7) & 3;        // se3mpc_set_rollout_variant(+128 / +256): 3 / 8 wavefronts (as se3mpc_rollout_obstacles_*)
+  const bool wide = forced_w == 2 || (forced_w == 0 && (long)nblk * nbatch * 8 <= 1024);
+  const int Kpad = (K + 7) / 8 * 8;
+#define SE3MPC_ITER_OBS(NN, REG, FL, WW)                                                                                            \
+  if (((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R) > 64 * 1024)                            \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_iterate_obstacles_kernel<R, NN, REG, FL, WW>),                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize,                                                            \
+                              (int)(((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R)));        \
+  hipLaunchKernelGGL((rollout_iterate_obstacles_kernel<R, NN, REG, FL, WW>), dim3(nblk, nbatch), dim3(64 * WW),                      \
+                     ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R), s, q, B, ld, iters, (R)step, \
+                     p0, v0, goal, Tin, Tout, cost_first, cost, gradT, spheres, K, (R)obstacle_weight, penalty, key, index_base)
+#define SE3MPC_ITER_OBS_W(NN, REG, FL) \
+  if (wide) { SE3MPC_ITER_OBS(NN, REG, FL, 8); } else { SE3MPC_ITER_OBS(NN, REG, FL, 3); }
+  if (has_reg) {
+    switch (N) {
+      case 6: SE3MPC_ITER_OBS_W(6, true, 7); break;
+      case 20: SE3MPC_ITER_OBS_W(20, true, 7); break;
+      default:
+        if constexpr (sizeof(R) == 4) {
+          if (N == 30) { SE3MPC_ITER_OBS_W(30, true, 7); }
+          else { SE3MPC_ITER_OBS_W(50, true, 7); }
+        }
+    }
+  } else if (has_bucket) {
+    if constexpr (sizeof(R) == 4) { SE3MPC_ITER_OBS_W(32, true, 15); }
+  } else {
+    SE3MPC_ITER_OBS_W(0, false, 7);
+  }
+#undef SE3MPC_ITER_OBS_W
+#undef SE3MPC_ITER_OBS
+  return launch_status("se3mpc_rollout_iterate_obstacles");
+}
+
+template <typename R>
 int projected_step_impl(const se3mpc_params* p, int B, int ld, double step, const R* T, const R* g, R* Tout, void* stream) {
   int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(R));
   if (rc) return rc;
@@ -1941,6 +2161,14 @@ using namespace se3mpc;
                                               R* cost, R* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream) {       \
     return rollout_iterate_impl<R>(p, B, ld, nbatch, iters, step, p0, v0, goal, T_in, T_out, cost_first, cost, gradT, wave_keys,  \
                                    index_base, stream);                                                                          \
+  }                                                                                                                      \
+  extern "C" int se3mpc_rollout_iterate_obstacles_##SUF(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, \
+                                                        const R* p0, const R* v0, const R* goal, const R* T_in, R* T_out,           \
+                                                        R* cost_first, R* cost, R* gradT, const R* spheres, int K,                  \
+                                                        double obstacle_weight, R* penalty, uint64_t* wave_keys,                    \
+                                                        uint32_t index_base, void* stream) {                                       \
+    return rollout_iterate_obstacles_impl<R>(p, B, ld, nbatch, iters, step, p0, v0, goal, T_in, T_out, cost_first, cost, gradT,      \
+                                             spheres, K, obstacle_weight, penalty, wave_keys, index_base, stream);                  \
   }                                                                                                                      \
   extern "C" int se3mpc_projected_step_##SUF(const se3mpc_params* p, int B, int ld, double step, const R* T, const R* gradT,      \
                                              R* T_out, void* stream) {                                                   \

@@ -129,27 +129,42 @@ def sharded_restart_solve(ops, params, p0, v0, goal, n_restarts: int, sigma: flo
     return dict(x=xw.to(torch.float64).cpu().numpy(), cost=ops.lib.key_cost(kh), restart=win, owner=owner)
 
 
-def shooting_samples(params, n_samples: int, sigma: float, seed: int, device, dtype):
-    """The thrust samples of :func:`sharded_shooting_plan` in lane layout (3N, n_samples): sample 0 = hover thrust, sample s > 0 = hover +
-    N(0, sigma) newtons.  Drawn on the device from ONE generator seeded with `seed`; every rank draws the whole set and keeps its shard, so the
-    samples -- and the winner -- do not depend on the number of ranks."""
+SAMPLE_BLOCK = 256      # thrust samples are drawn in blocks of this many columns, each from its own counter-seeded generator
+
+
+def shooting_samples(params, n_samples: int, sigma: float, seed: int, device, dtype, lo: int = 0, hi: Optional[int] = None):
+    """Columns [lo, hi) of the thrust samples of :func:`sharded_shooting_plan` in lane layout (3N, hi - lo): sample 0 = hover thrust,
+    sample s > 0 = hover + N(0, sigma) newtons.  Block b (samples b * SAMPLE_BLOCK ...) is drawn on the device from a generator seeded with
+    (seed, b), so a rank draws ONLY the blocks its shard touches -- O(shard), not O(n_samples) per rank -- and the samples, hence the
+    winner, do not depend on the number of ranks."""
     import torch
     N = params.horizon
-    g = torch.Generator(device=device)
-    g.manual_seed(int(seed))
-    T = torch.randn(3 * N, n_samples, generator=g, device=device, dtype=dtype) * float(sigma)
-    T[:, 0] = 0.0
+    hi = n_samples if hi is None else hi
+    if not 0 <= lo <= hi <= n_samples:
+        raise ValueError("shooting_samples: need 0 <= lo <= hi <= n_samples")
+    parts = []
+    for blk in range(lo // SAMPLE_BLOCK, (hi + SAMPLE_BLOCK - 1) // SAMPLE_BLOCK if hi > lo else lo // SAMPLE_BLOCK):
+        g = torch.Generator(device=device)
+        g.manual_seed((int(seed) * 1000003 + blk) & 0x7FFFFFFFFFFFFFFF)
+        t = torch.randn(3 * N, SAMPLE_BLOCK, generator=g, device=device, dtype=dtype) * float(sigma)
+        if blk == 0:
+            t[:, 0] = 0.0
+        c0, c1 = max(lo, blk * SAMPLE_BLOCK) - blk * SAMPLE_BLOCK, min(hi, (blk + 1) * SAMPLE_BLOCK) - blk * SAMPLE_BLOCK
+        parts.append(t[:, c0:c1])
+    T = torch.cat(parts, dim=1).contiguous() if parts else torch.zeros((3 * N, 0), device=device, dtype=dtype)
     T[2::3] += params.mass * params.gravity
     return T
 
 
 def sharded_shooting_plan(ops, params, p0, v0, goal, n_samples: int, iters: int = 16, step: float = 0.9, sigma: float = 2.0, seed: int = 0,
-                          precision: str = "f32") -> Dict[str, np.ndarray]:
+                          precision: str = "f32", spheres=None, obstacle_weight: float = 1000.0) -> Dict[str, np.ndarray]:
     """One problem, `n_samples` thrust sequences sharded over the ranks of the default process group -- the north_star's "sample batch
     shards across the GPUs with a single all-reduce for the argmin" on the shooting form: every rank draws its samples (sample 0 = hover
     thrust, sample s > 0 = hover + N(0, sigma) newtons; :func:`shooting_samples`: the result does not depend on the number of ranks), descends each of them `iters` projected-gradient iterations in ONE launch (se3mpc_rollout_iterate_*, thrust sequences in
     registers), folds the fused per-wavefront argmin keys, ONE all-reduce(MIN) of the 8-byte key, and the owner broadcasts the winning
-    thrust sequence (3N values).  Returns on every rank: T (N, 3), its cost, the winning sample and its owner."""
+    thrust sequence (3N values).  Returns on every rank: T (N, 3), its cost, the winning sample and its owner.
+    spheres: (K, 4) host rows (cx, cy, cz, r), replicated on every rank: the obstacle-aware loop (se3mpc_rollout_iterate_obstacles_*) --
+    the descent and the argmin see running cost + obstacle_weight * penalty."""
     import torch
     import torch.distributed as dist
     dist_on = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
@@ -163,10 +178,12 @@ def sharded_shooting_plan(ops, params, p0, v0, goal, n_samples: int, iters: int 
     best = torch.full((1,), -1, dtype=torch.int64, device=dev)
     Tout = None
     if R > 0:
-        lane = shooting_samples(params, n_samples, sigma, seed, dev, dt)[:, lo:hi].contiguous()
+        lane = shooting_samples(params, n_samples, sigma, seed, dev, dt, lo, hi)
         col = lambda a: torch.from_numpy(np.ascontiguousarray(np.tile(np.asarray(a, float).reshape(3, 1), (1, R)))).to(device=dev, dtype=dt)
         wk = torch.zeros(((R + 63) // 64,), dtype=torch.int64, device=dev)
-        out = ops.rollout_iterate(params, col(p0), col(v0), col(goal), lane, int(iters), float(step), want_grad=False, wave_keys=wk, index_base=lo)
+        sph = None if spheres is None else torch.from_numpy(np.ascontiguousarray(np.asarray(spheres, float).reshape(-1, 4))).to(device=dev, dtype=dt)
+        out = ops.rollout_iterate(params, col(p0), col(v0), col(goal), lane, int(iters), float(step), want_grad=False, wave_keys=wk, index_base=lo,
+                                  spheres=sph, obstacle_weight=obstacle_weight, want_penalty=False)
         Tout = out["T"]
         ops.reduce_keys(wk.view(1, -1), best)
     allreduce_min_keys(best)

@@ -297,11 +297,14 @@ class Ops:
         return cost, gradT, cmin, viol
 
     def rollout_iterate(self, params: Params, p0, v0, goal, T, iters: int, step: float, T_out=None, want_grad: bool = True,
-                        want_first_cost: bool = False, B: Optional[int] = None, out=None, wave_keys=None, index_base: int = 0):
+                        want_first_cost: bool = False, B: Optional[int] = None, out=None, wave_keys=None, index_base: int = 0,
+                        spheres=None, obstacle_weight: float = 1000.0, want_penalty: bool = True):
         """`iters` projected-gradient iterations of the shooting form in ONE launch (thrust sequences stay in registers), then one
         last evaluation.  Single batch: p0, v0, goal (3, ld), T (3N, ld); multi-batch (grid.y): leading batch axis on every operand.
         -> dict(T (like T), cost, gradT | None, cost_first | None).  ``out=(T_out, cost, gradT)`` reuses preallocated outputs;
-        T_out may be T itself (in place)."""
+        T_out may be T itself (in place).
+        spheres (K, 4) rows (cx, cy, cz, r): the obstacle-aware loop (se3mpc_rollout_iterate_obstacles_*: the build's extension) --
+        the objective gains obstacle_weight * sum max(0, -(|P_k - c_j|^2 - (r_j + safety_margin)^2))^2 and the dict a ``penalty`` entry."""
         N = params.horizon
         batched = T.ndim == 3
         nb = T.shape[0] if batched else 1
@@ -320,6 +323,17 @@ class Ops:
             gradT = self.be.empty(lead + (3 * N, ld), suf) if want_grad else None
         cost_first = self.be.empty(lead + (ld,), suf) if want_first_cost else None
         nB = self._B(ld, B)
+        if spheres is not None:
+            self.be.check(spheres, "spheres")
+            if spheres.ndim != 2 or spheres.shape[1] != 4 or spheres.shape[0] > SE3MPC_MAX_SPHERES or self.be.suffix(spheres) != suf:
+                raise ValueError(f"spheres: expected (K<={SE3MPC_MAX_SPHERES}, 4) {suf}, got {tuple(spheres.shape)}")
+            penalty = self.be.empty(lead + (ld,), suf) if want_penalty else None
+            self.lib.call("rollout_iterate_obstacles", suf, nB, ld, nb, int(iters), float(step), self.be.ptr(p0), self.be.ptr(v0),
+                          self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(T_out), self.be.ptr(cost_first),
+                          self.be.ptr(cost), self.be.ptr(gradT), self.be.ptr(spheres if spheres.shape[0] else None), spheres.shape[0],
+                          float(obstacle_weight), self.be.ptr(penalty), self.be.ptr(wave_keys), int(index_base), self.be.stream(),
+                          params=params)
+            return dict(T=T_out, cost=cost, gradT=gradT, cost_first=cost_first, penalty=penalty)
         self.lib.call("rollout_iterate", suf, nB, ld, nb, int(iters), float(step), self.be.ptr(p0), self.be.ptr(v0),
                       self.be.ptr(goal if params.has_goal else None), self.be.ptr(T), self.be.ptr(T_out), self.be.ptr(cost_first),
                       self.be.ptr(cost), self.be.ptr(gradT), self.be.ptr(wave_keys), int(index_base), self.be.stream(), params=params)
@@ -486,7 +500,7 @@ class Ops:
             raise ValueError("state: float64 (B, 12)")
         if saturation is not None:
             self.be.check(saturation, "saturation")
-            if tuple(saturation.shape) != (B,) or saturation.element_size() != 4 if hasattr(saturation, "element_size") else saturation.itemsize != 4:
+            if tuple(saturation.shape) != (B,) or not str(saturation.dtype).endswith("int32"):     # (a float32 (B,) array would be read as flag bits)
                 raise ValueError("saturation: int32 (B,)")
         self.lib.loop_call("controller_integral_update", suf, cp, B, self.be.ptr(vel_error), float(dt), self.be.ptr(saturation), self.be.ptr(state),
                            self.be.stream())

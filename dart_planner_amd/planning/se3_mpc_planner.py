@@ -327,14 +327,32 @@ class SE3MPCPlanner(BasePlanner):
                                          "body_rates", "thrusts")}
         return self._create_trajectory_from_solution(sol, time.time())
 
+    def _obstacle_table(self, obstacles) -> Optional[np.ndarray]:
+        """(K, 4) rows (cx, cy, cz, r) for the obstacle-aware loop: None / True = the planner's own list (add_obstacle, planner.py:183-187 --
+        what the cloud loop refreshes from the mapper every cycle, cloud/main_improved_threelayer.py:381-398), False = ignore it, an array =
+        those spheres.  None when there is nothing to avoid."""
+        if obstacles is False:
+            return None
+        if obstacles is None or obstacles is True:
+            if not self.obstacles:
+                return None
+            return np.array([[*np.asarray(to_float(c), float).reshape(3), float(r)] for c, r in self.obstacles], dtype=float)
+        sph = np.asarray(obstacles, float).reshape(-1, 4)
+        return sph if len(sph) else None
+
     def plan_shooting(self, current_state: DroneState, goal_position, n_samples: int = 8192, iters: int = 16, step: float = 0.9,
-                      sigma: float = 2.0, seed: int = 0, precision: str = "f32") -> Trajectory:
+                      sigma: float = 2.0, seed: int = 0, precision: str = "f32", obstacles=None,
+                      obstacle_weight: Optional[float] = None) -> Trajectory:
         """The shooting-form counterpart of :meth:`plan_trajectory` (the build's construct, like the restarts): `n_samples` thrust
         sequences around hover are each descended `iters` projected-gradient iterations on the device (ONE launch,
         ``se3mpc_rollout_iterate_*``; with several ranks the samples shard and one all-reduce(MIN) picks the winner,
         ``distributed.sharded_shooting_plan``), the best one is rolled out (``se3mpc_rollout_cost_grad_*`` with states) and its
         accelerations / attitudes / body rates / thrust magnitudes extracted (``se3mpc_extract_*``).  Unlike the reference's solve, whose
-        dynamics constraints never reach the optimiser, this plan satisfies the dynamics by construction."""
+        dynamics constraints never reach the optimiser, this plan satisfies the dynamics by construction.
+        obstacles: the sphere list the descent avoids (``_obstacle_table``: by default the planner's own, which the reference keeps and
+        never uses) through the obstacle-aware loop ``se3mpc_rollout_iterate_obstacles_*``: the objective gains
+        obstacle_weight * sum max(0, -(|P_k - c_j|^2 - (r_j + safety_margin)^2))^2 (obstacle_weight defaults to the config's, planner.py:63);
+        ``last_result["penalty"]`` is what is left of it at the returned plan (0 = every margin kept)."""
         import torch
         import torch.distributed as dist
         from ..distributed import sharded_shooting_plan
@@ -344,10 +362,13 @@ class SE3MPCPlanner(BasePlanner):
         N = self.se3_config.prediction_horizon
         p0 = np.asarray(to_float(current_state.position), float)
         v0 = np.asarray(to_float(current_state.velocity), float)
+        sph = self._obstacle_table(obstacles)
+        w_obs = float(self.se3_config.obstacle_weight if obstacle_weight is None else obstacle_weight)
         single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
         if single and getattr(ops.be, "graph_capable", False):
-            return self._plan_shooting_captured(ops, prm, p0, v0, int(n_samples), int(iters), float(step), float(sigma), int(seed), precision)
-        best = sharded_shooting_plan(ops, prm, p0, v0, self.goal_position, n_samples, iters, step, sigma, seed, precision)
+            return self._plan_shooting_captured(ops, prm, p0, v0, int(n_samples), int(iters), float(step), float(sigma), int(seed), precision, sph, w_obs)
+        best = sharded_shooting_plan(ops, prm, p0, v0, self.goal_position, n_samples, iters, step, sigma, seed, precision, spheres=sph,
+                                     obstacle_weight=w_obs)
         dev = ops.be.device
         col = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, float).reshape(-1, 1))).to(dev)
         T = col(best["T"].reshape(-1))
@@ -356,11 +377,16 @@ class SE3MPCPlanner(BasePlanner):
         h = lambda a, shape: ops.be.to_host(a)[:, 0].reshape(shape).astype(float)
         self.last_result = dict(cost=float(ops.be.to_host(cost)[0]), sample=int(best["sample"]), owner=int(best["owner"]), n_samples=int(n_samples),
                                 iters=int(iters), T=best["T"])
+        if sph is not None:
+            # what is left of the penalty at the returned plan (0 = every sphere's margin kept at every step)
+            o = ops.rollout_iterate(prm, col(p0), col(v0), col(self.goal_position), T, 0, 0.0, want_grad=False, spheres=col(sph.reshape(-1)).reshape(-1, 4).contiguous(),
+                                    obstacle_weight=w_obs)
+            self.last_result.update(penalty=float(ops.be.to_host(o["penalty"])[0]), cost_with_penalty=float(ops.be.to_host(o["cost"])[0]))
         sol = {"positions": h(P, (N, 3)), "velocities": h(V, (N, 3)), "thrust_vectors": best["T"], "accelerations": h(acc, (N, 3)),
                "attitudes": h(att, (N, 3)), "body_rates": h(rates, (N, 3)), "thrusts": h(thr, (N,))}
         return self._create_trajectory_from_solution(sol, time.time())
 
-    def _plan_shooting_captured(self, ops, prm, p0, v0, n_samples, iters, step, sigma, seed, precision) -> Trajectory:
+    def _plan_shooting_captured(self, ops, prm, p0, v0, n_samples, iters, step, sigma, seed, precision, sph=None, w_obs=1000.0) -> Trajectory:
         """plan_shooting on one rank as ONE hipGraph replay: 72 B in through a pinned buffer, the sample set (fixed by its seed) resident,
         iterate -> fold the argmin keys -> select the winner's thrust column BY ITS DEVICE-SIDE KEY -> roll it out with states -> extract,
         one packed result back to a pinned buffer; the host synchronises once.  Same launches, same numbers as the eager path
@@ -368,7 +394,8 @@ class SE3MPCPlanner(BasePlanner):
         import torch
         from ..distributed import shooting_samples
         N = prm.horizon
-        key = (N, n_samples, iters, step, sigma, seed, precision, bytes(prm))
+        K = 0 if sph is None else len(sph)
+        key = (N, n_samples, iters, step, sigma, seed, precision, bytes(prm), K, w_obs)
         g = self._shooting_graphs.get(key) if hasattr(self, "_shooting_graphs") else None
         if g is None:
             if not hasattr(self, "_shooting_graphs"):
@@ -379,12 +406,20 @@ class SE3MPCPlanner(BasePlanner):
                       h_out=torch.zeros(19 * N + 1, dtype=torch.float64).pin_memory(), h_key=torch.zeros(1, dtype=torch.int64).pin_memory(),
                       samples=shooting_samples(prm, n_samples, sigma, seed, dev, dt), wk=torch.zeros(((n_samples + 63) // 64,), dtype=torch.int64, device=dev),
                       best=torch.zeros(1, dtype=torch.int64, device=dev))
+            if K:                                                                  # the sphere table travels with every plan (the mapper refreshes it each cycle)
+                io.update(h_sph=torch.zeros((K, 4), dtype=torch.float64).pin_memory(), d_sph=torch.zeros((K, 4), dtype=torch.float64, device=dev),
+                          h_pen=torch.zeros(2, dtype=torch.float64).pin_memory())
 
             def body():
                 io["d_in"].copy_(io["h_in"], non_blocking=True)
                 c = io["d_in"].to(dt).view(3, 3, 1)
                 wide = c.expand(3, 3, n_samples).contiguous()
-                out = ops.rollout_iterate(prm, wide[0], wide[1], wide[2], io["samples"], iters, step, want_grad=False, wave_keys=io["wk"], index_base=0)
+                sph_d = None
+                if K:
+                    io["d_sph"].copy_(io["h_sph"], non_blocking=True)
+                    sph_d = io["d_sph"].to(dt)
+                out = ops.rollout_iterate(prm, wide[0], wide[1], wide[2], io["samples"], iters, step, want_grad=False, wave_keys=io["wk"], index_base=0,
+                                          spheres=sph_d, obstacle_weight=w_obs, want_penalty=False)
                 ops.reduce_keys(io["wk"].view(1, -1), io["best"])
                 tw = out["T"].index_select(1, io["best"] & 0xFFFFFFFF).to(torch.float64)   # the key's low word is the sample index (se3mpc_key_index)
                 one = io["d_in"].view(3, 3, 1)                                     # the winner is rolled out and extracted in f64, as the eager path does
@@ -393,6 +428,9 @@ class SE3MPCPlanner(BasePlanner):
                 packed = torch.cat([x.reshape(-1) for x in (P, V, tw, acc, att, rates, thr, cost)])
                 io["h_out"].copy_(packed, non_blocking=True)
                 io["h_key"].copy_(io["best"], non_blocking=True)
+                if K:                                                              # the winner's remaining penalty (f64, like its rollout)
+                    o = ops.rollout_iterate(prm, one[0], one[1], one[2], tw, 0, 0.0, want_grad=False, spheres=io["d_sph"], obstacle_weight=w_obs)
+                    io["h_pen"].copy_(torch.cat([o["penalty"].reshape(-1), o["cost"].reshape(-1)]), non_blocking=True)
 
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -409,12 +447,16 @@ class SE3MPCPlanner(BasePlanner):
         graph, io = g
         io["h_in"][0:3] = torch.from_numpy(p0); io["h_in"][3:6] = torch.from_numpy(v0)
         io["h_in"][6:9] = torch.from_numpy(np.asarray(self.goal_position, float))
+        if K:
+            io["h_sph"].copy_(torch.from_numpy(np.ascontiguousarray(sph)))
         graph.replay()
         torch.cuda.current_stream(ops.be.device).synchronize()
         r = io["h_out"].numpy()
         kh = int(io["h_key"].numpy()[0]) & 0xFFFFFFFFFFFFFFFF
         blk = lambda i: r[3 * N * i:3 * N * (i + 1)].reshape(N, 3).copy()
         self.last_result = dict(cost=float(r[19 * N]), sample=int(ops.lib.key_index(kh)), owner=0, n_samples=n_samples, iters=iters, T=blk(2))
+        if K:
+            self.last_result.update(penalty=float(io["h_pen"][0]), cost_with_penalty=float(io["h_pen"][1]))
         sol = {"positions": blk(0), "velocities": blk(1), "thrust_vectors": blk(2), "accelerations": blk(3), "attitudes": blk(4),
                "body_rates": blk(5), "thrusts": r[18 * N:19 * N].copy()}
         return self._create_trajectory_from_solution(sol, time.time())

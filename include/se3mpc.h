@@ -228,6 +228,22 @@ int se3mpc_rollout_iterate_f32(const se3mpc_params* p, int B, int ld, int nbatch
 int se3mpc_rollout_iterate_f64(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const double* p0,
                                const double* v0, const double* goal, const double* T_in, double* T_out, double* cost_first, double* cost,
                                double* gradT, uint64_t* wave_keys, uint32_t index_base, void* stream);
+/* The obstacle-aware iteration loop (BASELINE config 3 inside the loop): se3mpc_rollout_iterate_* on the objective
+ *     running cost (planner.py:516-550 on the rolled-out states) + obstacle_weight * sum_k sum_j max(0, -c_kj)^2,
+ *     c_kj = |P_k - c_j|^2 - (r_j + safety_margin)^2      (the reference's sphere residual, planner.py:499-514)
+ * -- the BUILD'S EXTENSION: the reference forms these residuals and never hands them to its solver (:250 vs :256-268; its
+ * obstacle_weight, :63 = 1000, is never read).  The exact gradient of the penalty reaches the thrust sequence through the same
+ * adjoint sweep.  spheres: [K][4] rows (cx, cy, cz, r) as se3mpc_rollout_obstacles_* (0 <= K <= SE3MPC_MAX_SPHERES; K = 0 is the
+ * plain loop's numbers at the obstacle form's speed).  cost / cost_first include the penalty; penalty: NULL or [B] = the penalty
+ * alone at T_out (0: the plan keeps the margin of every sphere at every step).  Everything else as se3mpc_rollout_iterate_*. */
+int se3mpc_rollout_iterate_obstacles_f32(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const float* p0,
+                                         const float* v0, const float* goal, const float* T_in, float* T_out, float* cost_first,
+                                         float* cost, float* gradT, const float* spheres, int K, double obstacle_weight,
+                                         float* penalty, uint64_t* wave_keys, uint32_t index_base, void* stream);
+int se3mpc_rollout_iterate_obstacles_f64(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const double* p0,
+                                         const double* v0, const double* goal, const double* T_in, double* T_out, double* cost_first,
+                                         double* cost, double* gradT, const double* spheres, int K, double obstacle_weight,
+                                         double* penalty, uint64_t* wave_keys, uint32_t index_base, void* stream);
 int se3mpc_projected_step_f32(const se3mpc_params* p, int B, int ld, double step, const float* T, const float* gradT, float* T_out,
                               void* stream);
 int se3mpc_projected_step_f64(const se3mpc_params* p, int B, int ld, double step, const double* T, const double* gradT, double* T_out,

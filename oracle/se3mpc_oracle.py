@@ -419,6 +419,29 @@ def rollout_cost_grad(p0, v0, goal, T, cfg: OracleConfig):
     return cost, G
 
 
+def obstacle_penalty_grad(p0, v0, T, spheres, cfg: OracleConfig, obstacle_weight: float):
+    """The build's obstacle-aware shooting objective (its EXTENSION: the reference builds the sphere residuals
+    c_kj = |P_k - c_j|^2 - (r_j + safety_margin)^2 of planner.py:499-514 and then drops them, :250 vs :256-268; obstacle_weight,
+    :63, is never read):  penalty = obstacle_weight * sum_k sum_j max(0, -c_kj)^2  on the ROLLED-OUT positions, and its exact
+    gradient wrt the thrust sequence.  The gradient is written in closed form -- dP_k/dT_j = dt^2/m (k - j - 1/2) for j < k for
+    this double integrator -- i.e. not with the adjoint recurrences the kernel runs, so the two check each other.
+    spheres: (K, 4) rows (cx, cy, cz, r).  Batched over leading axes.  Returns (penalty (...), dpenalty/dT (..., N, 3))."""
+    N, dt, m = cfg.prediction_horizon, cfg.dt, cfg.mass
+    T = np.asarray(T, float)
+    P, _ = rollout(p0, v0, T, cfg)
+    sp = np.asarray(spheres, float).reshape(-1, 4)
+    if sp.shape[0] == 0:
+        return np.zeros(T.shape[:-2]), np.zeros_like(T)
+    d = P[..., :, None, :] - sp[:, :3]                                   # (..., N, K, 3)
+    c = np.sum(d * d, axis=-1) - (sp[:, 3] + cfg.safety_margin) ** 2      # (..., N, K)   planner.py:505-512
+    h = np.maximum(0.0, -c)
+    pen = obstacle_weight * np.sum(h * h, axis=(-1, -2))
+    q = -4.0 * obstacle_weight * np.sum(h[..., None] * d, axis=-2)        # dpen/dP_k   (..., N, 3)
+    kk, jj = np.arange(N)[:, None], np.arange(N)[None, :]
+    J = np.where(kk > jj, dt * dt / m * (kk - jj - 0.5), 0.0)             # dP_k/dT_j, (k, j)
+    return pen, np.einsum("kj,...ka->...ja", J, q)
+
+
 # --------------------------------------------------------------------------- f-2: obstacle source
 def local_grid_positions(centre, size: float, resolution: float) -> np.ndarray:
     """Grid cell centres in the order of ExplicitGeometricMapper.get_local_occupancy_grid

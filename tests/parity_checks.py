@@ -354,6 +354,96 @@ def check_rollout_iterate(h: Harness, N: int, B: int, seed: int = 0, iters: int 
     return bitwise
 
 
+def oracle_iterate_obstacles(p0, v0, goal, T, spheres, cfg, iters, step, w_obs):
+    """Host-chained float64 reference of se3mpc_rollout_iterate_obstacles_*: running cost + obstacle penalty (oracle.obstacle_penalty_grad,
+    closed-form chain rule), projected steps.  -> T_final, cost_final, grad_final, cost_first, penalty_final"""
+    lo, hi = thrust_box(cfg)
+    T = np.array(T, dtype=float)
+    c0 = None
+    for _ in range(iters):
+        c, g = orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+        pen, gp = orc.obstacle_penalty_grad(p0, v0, T, spheres, cfg, w_obs)
+        c0 = (c + pen) if c0 is None else c0
+        T = np.clip(T - step * (g + gp), lo, hi)
+    c, g = orc.rollout_cost_grad(p0, v0, goal, T, cfg)
+    pen, gp = orc.obstacle_penalty_grad(p0, v0, T, spheres, cfg, w_obs)
+    return T, c + pen, g + gp, ((c + pen) if c0 is None else c0), pen
+
+
+def check_rollout_iterate_obstacles(h: Harness, N: int, B: int, seed: int = 0, iters: int = 4, K: int = 5, dt: float = 0.1,
+                                    step: float = 2e-3, w_obs: float = 40.0):
+    """The obstacle-aware iteration loop (the build's extension: running cost + w_obs * sum max(0, -c_kj)^2 on the rolled-out positions):
+    (1) against the host-chained oracle whose penalty gradient is a closed-form chain rule, not an adjoint sweep; (2) K iterations in
+    one launch == K one-iteration launches, bit for bit; (3) iters = 0: cost = rollout cost + penalty, the penalty output, cost_first;
+    (4) no spheres == the plain loop; (5) 3 and 8 wavefronts per workgroup give the same bits; (6) multi-batch == batch by batch;
+    (7) spheres far away: zero penalty, the plain loop's numbers.  dt = 0.1 by default so that the horizon covers metres (at the
+    reference's 1/400 s a 30-step plan spans 7 cm and nothing but a sphere on top of the start would matter)."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N, dt=dt)
+    cfg = oracle_cfg(prm)
+    t = h.tol
+    p0, v0, goal, T = random_batch(rng, B, N, spread=3.0)
+    p0 = p0 * 0.1; goal = goal * 0.2                                   # starts within +-2 m, goals within +-4 m: the spheres are in the way
+    sph = np.concatenate([rng.uniform(-3, 3, (K, 3)), rng.uniform(0.3, 1.0, (K, 1))], axis=1)
+    r = lambda a: np.asarray(a).astype(h.dt).astype(float)
+    Tr, cr, gr, c0r, penr = oracle_iterate_obstacles(r(p0), r(v0), r(goal), r(T), r(sph), cfg, iters, step, w_obs)
+    assert np.any(penr > 0), "the check wants trajectories inside the spheres' margins"
+    lp0, lv0, lg, lT = h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B)
+    dsph = h.to_dev(np.ascontiguousarray(sph.astype(h.dt)))
+    run = lambda Tin, it, **kw: h.ops.rollout_iterate(prm, lp0, lv0, lg, Tin, it, step, spheres=dsph, obstacle_weight=w_obs, **kw)
+    out = run(lT, iters, want_first_cost=True)
+    scale = 50.0 if h.dt == np.float32 else 1.0
+    Tk = h.unlane(out["T"], (B, N, 3))
+    vec_close(Tk, Tr, t["vec_rel"] * scale, "iterated T (obstacles)")
+    ch = h.to_host(out["cost"]).astype(float)
+    assert np.max(np.abs(ch - cr) / np.abs(cr)) <= t["cost_rel"] * scale, "iterated cost (obstacles)"
+    vec_close(h.unlane(out["gradT"], (B, N, 3)), gr, t["vec_rel"] * scale, "gradient at the final T (obstacles)")
+    assert np.max(np.abs(h.to_host(out["cost_first"]).astype(float) - c0r) / np.abs(c0r)) <= t["cost_rel"] * 4, "cost at T_in (obstacles)"
+    ph = h.to_host(out["penalty"]).astype(float)
+    assert np.max(np.abs(ph - penr)) <= t["cost_rel"] * scale * max(1.0, float(np.max(penr))), "penalty"
+    # (2) one launch == `iters` launches of one iteration
+    Tc = lT
+    for _ in range(iters):
+        Tc = run(Tc, 1, want_grad=False)["T"]
+    last = run(Tc, 0)
+    assert np.array_equal(h.to_host(Tc), h.to_host(out["T"])), "K iterations in one launch != K one-iteration launches (obstacles)"
+    assert np.array_equal(h.to_host(last["cost"]), h.to_host(out["cost"])) and np.array_equal(h.to_host(last["gradT"]), h.to_host(out["gradT"]))
+    # (3) iters = 0 against the oracle's two parts
+    o0 = run(lT, 0, want_first_cost=True)
+    c_run, g_run = orc.rollout_cost_grad(r(p0), r(v0), r(goal), r(T), cfg)
+    pen0, gp0 = orc.obstacle_penalty_grad(r(p0), r(v0), r(T), r(sph), cfg, w_obs)
+    assert np.allclose(h.to_host(o0["cost"]).astype(float), c_run + pen0, rtol=t["cost_rel"] * 4, atol=0)
+    assert np.array_equal(h.to_host(o0["cost"]), h.to_host(o0["cost_first"])) and np.array_equal(h.to_host(o0["T"]), h.to_host(lT))
+    vec_close(h.unlane(o0["gradT"], (B, N, 3)), g_run + gp0, t["vec_rel"] * 4, "iters = 0 gradient (obstacles)")
+    # (4) no spheres, and (7) spheres out of reach: the plain loop
+    plain = h.ops.rollout_iterate(prm, lp0, lv0, lg, lT, iters, step)
+    none = h.ops.rollout_iterate(prm, lp0, lv0, lg, lT, iters, step, spheres=h.to_dev(np.zeros((0, 4), dtype=h.dt)), obstacle_weight=w_obs)
+    far = h.ops.rollout_iterate(prm, lp0, lv0, lg, lT, iters, step, spheres=h.to_dev(np.array([[500.0, 500.0, 500.0, 1.0]], dtype=h.dt)), obstacle_weight=w_obs)
+    for o in (none, far):
+        assert np.all(h.to_host(o["penalty"]) == 0)
+        vec_close(h.to_host(o["T"]).astype(float), h.to_host(plain["T"]).astype(float), 2e-6 if h.dt == np.float32 else 1e-13, "no obstacle in reach vs the plain loop")
+        assert np.allclose(h.to_host(o["cost"]), h.to_host(plain["cost"]), rtol=2e-6 if h.dt == np.float32 else 1e-13, atol=0)
+    # (5) 3 / 8 wavefronts per workgroup
+    res = {}
+    for sel in (128, 256):
+        h.ops.lib.set_rollout_variant(sel)
+        try:
+            res[sel] = run(lT, iters)
+        finally:
+            h.ops.lib.set_rollout_variant(0)
+    for nm in ("T", "gradT"):
+        assert np.array_equal(h.to_host(res[128][nm]), h.to_host(res[256][nm])), ("3 vs 8 wavefronts", nm)
+    assert np.allclose(h.to_host(res[128]["cost"]), h.to_host(res[256]["cost"]), rtol=t["cost_rel"], atol=0)      # (the penalty shares are summed in another order)
+    # (6) multi-batch launch, in place
+    nb = 2
+    st = lambda a, rows: h.to_dev(np.ascontiguousarray(np.transpose(np.stack([a, a[::-1]]).reshape(nb, B, rows), (0, 2, 1)).astype(h.dt)))
+    dp0, dv0, dgoal, dT = st(p0, 3), st(v0, 3), st(goal, 3), st(T.reshape(B, -1), 3 * N)
+    ob = h.ops.rollout_iterate(prm, dp0, dv0, dgoal, dT, iters, step, T_out=dT, spheres=dsph, obstacle_weight=w_obs)
+    for nm in ("T", "cost", "gradT", "penalty"):
+        assert np.array_equal(h.to_host(ob[nm])[0], h.to_host(out[nm])), ("batched iterate (obstacles)", nm)
+    return float(np.max(penr))
+
+
 def check_key_nonfinite(h: Harness):
     """Packed argmin keys with non-finite costs: NaN of either sign must never win (a negative NaN would sort below
     -inf in a plain sign-magnitude map) nor pass for the dead-lane sentinel; -inf wins over everything real; +inf

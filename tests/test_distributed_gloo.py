@@ -102,6 +102,72 @@ def test_two_rank_restart_argmin_matches_single_process():
         assert keys == [((0x80000000 | 100) << 32) | 1, ((0x80000000 | 49) << 32) | 12]
 
 
+SHOOT3 = dict(n_samples=700, iters=3, step=2e-3, sigma=3.0, seed=5, precision="f64")        # 700 = 234 + 233 + 233: the remainder path; 3 sample blocks
+SPHERES3 = [[1.5, -0.5, 2.0, 0.8], [3.0, 0.5, 2.5, 0.6]]
+
+
+def _worker3(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd import distributed as D
+    D.init_distributed("gloo")
+    drawn = []
+    real_randn = torch.randn
+
+    def counting_randn(*a, **k):
+        drawn.append(int(np.prod(a[:2])))
+        return real_randn(*a, **k)
+
+    torch.randn = counting_randn
+    try:
+        shoot = D.sharded_shooting_plan(_ops(), Params.reference_defaults(horizon=6, dt=0.1), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"],
+                                        spheres=SPHERES3, obstacle_weight=30.0, **SHOOT3)
+    finally:
+        torch.randn = real_randn
+    q.put((rank, shoot, sum(drawn)))
+    torch.distributed.destroy_process_group()
+
+
+def test_three_rank_shooting_plan_with_obstacles_and_a_remainder():
+    """world_size 3, a sample count the world does not divide (shard_bounds' remainder path through sharded_shooting_plan), the
+    obstacle-aware loop: every rank returns the single-process plan, and draws only the sample blocks its shard touches."""
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd import distributed as D
+    single = D.sharded_shooting_plan(_ops(), Params.reference_defaults(horizon=6, dt=0.1), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"],
+                                     spheres=SPHERES3, obstacle_weight=30.0, **SHOOT3)
+    blind = D.sharded_shooting_plan(_ops(), Params.reference_defaults(horizon=6, dt=0.1), PROBLEM["p0"], PROBLEM["v0"], PROBLEM["goal"], **SHOOT3)
+    assert not np.array_equal(single["T"], blind["T"])                 # the spheres do change the plan
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in procs), key=lambda g: g[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bounds = [D.shard_bounds(SHOOT3["n_samples"], r, 3) for r in range(3)]
+    assert [hi - lo for lo, hi in bounds] == [234, 233, 233]
+    for rank, shoot, drawn in got:
+        assert shoot["sample"] == single["sample"] and shoot["cost"] == single["cost"] and np.array_equal(shoot["T"], single["T"])
+        assert shoot["owner"] == next(r for r, (lo, hi) in enumerate(bounds) if lo <= single["sample"] < hi)
+        lo, hi = bounds[rank]
+        blocks = (hi + D.SAMPLE_BLOCK - 1) // D.SAMPLE_BLOCK - lo // D.SAMPLE_BLOCK
+        assert drawn == blocks * D.SAMPLE_BLOCK * 18 and drawn < 18 * (SHOOT3["n_samples"] + D.SAMPLE_BLOCK)    # O(shard), not O(n_samples)
+    assert got[0][2] + got[1][2] + got[2][2] <= 18 * (SHOOT3["n_samples"] + 3 * D.SAMPLE_BLOCK)
+
+
+def test_shooting_samples_do_not_depend_on_the_shard():
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd import distributed as D
+    prm = Params.reference_defaults(horizon=6)
+    full = D.shooting_samples(prm, 700, 2.0, 11, torch.device("cpu"), torch.float64)
+    assert full.shape == (18, 700) and torch.all(full[:, 0] == torch.tensor([0.0, 0.0, prm.mass * prm.gravity] * 6, dtype=torch.float64))
+    for lo, hi in ((0, 700), (0, 1), (255, 257), (256, 512), (300, 301), (511, 700), (700, 700)):
+        assert torch.equal(D.shooting_samples(prm, 700, 2.0, 11, torch.device("cpu"), torch.float64, lo, hi), full[:, lo:hi])
+
+
 def test_bench_gpus_n_starts_n_ranks_by_itself():
     """`python bench.py --gpus 2` without a torchrun environment must start 2 ranks as a child process and report
     them (dry run: rank plumbing only, gloo, no HIP) -- a driver that calls bench.py directly gets a real N-rank run

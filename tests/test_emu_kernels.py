@@ -42,6 +42,13 @@ def test_rollout_iterate(emu_ops, dt, N, B):
     pc.check_rollout_iterate(harness(emu_ops, dt), N, B, seed=N, iters=4)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(6, 70), (30, 40), (7, 9), (24, 65)])
+def test_rollout_iterate_obstacles(emu_ops, dt, N, B):
+    # N = 6 / 30: exact-N register kernels (f64: 30 takes the through-memory path), 24: the 32-step bucket (f32), 7: through memory
+    pc.check_rollout_iterate_obstacles(harness(emu_ops, dt), N, B, seed=N, iters=3)
+
+
 def test_keys_with_nonfinite_costs(emu_ops):
     pc.check_key_nonfinite(harness(emu_ops, np.float32))
 

@@ -161,6 +161,43 @@ def test_controller_mirror_private_steps(gpu_ops):
         assert np.allclose(b3o, b3) and np.allclose(Rm.T @ Rm, np.eye(3), atol=1e-12), method
 
 
+def test_controller_mirror_reset_and_quaternion_states(gpu_ops):
+    """(1) reset() after a failsafe: the reference's reset (controller.py:853-869) clears the integral, the clock and the failsafe flags but
+    NOT the gains its failsafe halved in place on self.config (:817-821) -- the mirror's halving count (word 10 of the device record)
+    survives.  (2) A quaternion attitude (controller.py:785-803: normalised; identity below 1e-6) gives the command of the same attitude
+    in Euler angles, whatever the quaternion's length."""
+    from dart_planner_amd.control.geometric_controller import GeometricController
+    from dart_planner_amd.common.types import DroneState
+    c = GeometricController(tuning_profile="sitl_optimized"); c._ops = gpu_ops
+    st = DroneState(timestamp=1.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.zeros(3), attitude=np.zeros(3), angular_velocity=np.zeros(3))
+    c.compute_control(st, np.array([0.5, 0.0, 1.0]), np.zeros(3), np.zeros(3))
+    c._set_words(10, [2.0])                                      # two failsafe halvings happened
+    c._set_words(0, [0.3, -0.2, 0.1]); c._set_flag_bits(1, 1)
+    c.reset()
+    assert c._word(10) == 2.0 and np.all(c.integral_vel_error == 0) and np.isnan(c._word(3)) and not (int(c._word(11)) & 1)
+    fresh = GeometricController(tuning_profile="sitl_optimized"); fresh._ops = gpu_ops
+    fresh._set_words(10, [2.0])
+    a = c.compute_control(st, np.array([0.5, 0.0, 1.0]), np.zeros(3), np.zeros(3))
+    b = fresh.compute_control(st, np.array([0.5, 0.0, 1.0]), np.zeros(3), np.zeros(3))
+    assert a.thrust == b.thrust and np.array_equal(np.asarray(a.torque), np.asarray(b.torque))
+    # quaternion attitudes
+    roll, pitch, yaw = 0.2, -0.1, 0.7
+    cr, sr, cp_, sp_, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw / 2), np.sin(yaw / 2)
+    quat = np.array([cr * cp_ * cy + sr * sp_ * sy, sr * cp_ * cy - cr * sp_ * sy, cr * sp_ * cy + sr * cp_ * sy, cr * cp_ * sy - sr * sp_ * cy])
+    out = []
+    for att in (np.array([roll, pitch, yaw]), quat, 3.0 * quat, 1e-9 * quat):
+        g = GeometricController(tuning_profile="sitl_optimized"); g._ops = gpu_ops
+        s2 = DroneState(timestamp=1.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.array([0.1, 0.0, 0.0]), attitude=att, angular_velocity=np.array([0.01, 0.02, 0.03]))
+        cmd = g.compute_control(s2, np.array([0.5, 0.2, 1.2]), np.zeros(3), np.zeros(3))
+        out.append(np.concatenate([[cmd.thrust], np.asarray(cmd.torque, float)]))
+    np.testing.assert_allclose(out[1], out[0], rtol=1e-12, atol=1e-14)
+    np.testing.assert_allclose(out[2], out[0], rtol=1e-12, atol=1e-14)          # the length of the quaternion does not matter
+    ident = GeometricController(tuning_profile="sitl_optimized"); ident._ops = gpu_ops
+    s3 = DroneState(timestamp=1.0, position=np.array([0.0, 0.0, 1.0]), velocity=np.array([0.1, 0.0, 0.0]), attitude=np.zeros(3), angular_velocity=np.array([0.01, 0.02, 0.03]))
+    cmd = ident.compute_control(s3, np.array([0.5, 0.2, 1.2]), np.zeros(3), np.zeros(3))
+    np.testing.assert_allclose(out[3], np.concatenate([[cmd.thrust], np.asarray(cmd.torque, float)]), rtol=1e-12, atol=1e-14)   # |q| < 1e-6: identity
+
+
 def test_closed_loop_reproduces_reference_loops(gpu_ops, golden_controller):
     data, meta = golden_controller
     worst = cc.check_closed_loops_golden(harness(gpu_ops, np.float64), data, meta)

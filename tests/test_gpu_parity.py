@@ -448,6 +448,99 @@ def test_wave_ops_selftest(gpu_ops):
         assert ops.decode_key(key)[0] == pos == int(torch.argmin(cost))
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(6, 300), (20, 257), (30, 1000), (50, 129), (7, 9), (24, 130), (64, 65), (1, 5)])
+def test_rollout_iterate_obstacles(gpu_ops, dt, N, B):
+    """The obstacle-aware iteration loop (running cost + obstacle_weight * sum max(0, -c_kj)^2; the build's extension) at the horizons the
+    plain loop is checked at: host-chained oracle with a closed-form penalty gradient, K-in-one == K x 1 bit for bit, 3 == 8 wavefronts,
+    no sphere in reach == the plain loop, multi-batch == batch by batch."""
+    worst_pen = pc.check_rollout_iterate_obstacles(harness(gpu_ops, dt), N, B, seed=N, iters=5, K=min(5 + N // 4, 16))
+    print(f"N={N} {np.dtype(dt).name}: largest penalty in the batch {worst_pen:.3g}")
+
+
+def test_rollout_iterate_obstacles_full_size(gpu_ops):
+    """BASELINE config 3 inside the loop: horizon 50, 8192 trajectories, 16 spheres, 16 iterations in ONE launch == 16 one-iteration
+    launches bit for bit; a 128-trajectory sample against the host-chained oracle; the penalty never grows along the descent of a
+    trajectory that starts inside a margin (weights chosen so that the step is a descent step)."""
+    import torch
+    N, B, K, iters, step, w = 50, 8192, 16, 16, 2e-4, 200.0          # a step inside the contraction regime: 1e-3 amplifies an input perturbation 3e4 x in 16 iterations (oracle, f64)
+    prm = pc.Params.reference_defaults(horizon=N, dt=0.05)
+    cfg = pc.oracle_cfg(prm)
+    rng = np.random.default_rng(2)
+    p0, v0, goal, T = pc.random_batch(rng, B, N, spread=2.0)
+    p0 *= 0.15; goal *= 0.3
+    sph = np.concatenate([np.round(rng.uniform(-4, 4, (K, 3)) * 2) / 2, np.full((K, 1), 1.0)], axis=1)     # mapper-style: radius 1.0, 0.5 m grid
+    h = harness(gpu_ops, np.float32)
+    lane = lambda a: h.lane(a, B)
+    dsph = h.to_dev(sph.astype(np.float32))
+    run = lambda Tin, it, **kw: gpu_ops.rollout_iterate(prm, lane(p0), lane(v0), lane(goal), Tin, it, step, spheres=dsph, obstacle_weight=w, **kw)
+    lT = lane(T)
+    out = run(lT, iters, want_first_cost=True)
+    Tc = lT
+    for _ in range(iters):
+        Tc = run(Tc, 1, want_grad=False)["T"]
+    assert torch.equal(Tc, out["T"])
+    r = lambda a: np.asarray(a).astype(np.float32).astype(float)
+    sub = slice(0, 128)
+    Tr, cr, gr, c0r, penr = pc.oracle_iterate_obstacles(r(p0[sub]), r(v0[sub]), r(goal[sub]), r(T[sub]), r(sph), cfg, iters, step, w)
+    Tk = out["T"].cpu().numpy().T.reshape(B, N, 3)[sub].astype(float)
+    pc.vec_close(Tk, Tr, 5e-6 * 200, "8192 x 16 iterations vs oracle")
+    assert np.max(np.abs(out["penalty"].cpu().numpy()[sub] - penr)) <= 1e-3 * max(1.0, penr.max())
+    pen0 = run(lT, 0)["penalty"].cpu().numpy()
+    pen1 = out["penalty"].cpu().numpy()
+    inside = pen0 > 0
+    print(f"config 3 inside the loop: {int(inside.sum())} of {B} trajectories start inside a margin; mean penalty {pen0[inside].mean():.3g} -> {pen1[inside].mean():.3g}")
+    assert inside.sum() > 100 and pen1[inside].mean() < 0.95 * pen0[inside].mean()
+    assert np.all(out["cost"].cpu().numpy() <= out["cost_first"].cpu().numpy() * (1 + 1e-5))
+
+
+def test_shooting_plan_avoids_the_mappers_obstacle(gpu_ops):
+    """plan_shooting with the planner's obstacle list (filled from the device voxel map the way the reference's cloud loop does it,
+    cloud/main_improved_threelayer.py:381-398) against the obstacle-blind plan: the blind plan flies through the obstacle and is rejected by
+    the mapper's is_trajectory_safe (mapper.py:195-219); the obstacle-aware one is accepted.  dt = 0.1 s (a 10 Hz timing manager) so that a
+    30-step plan covers 3 s."""
+    from dart_planner_amd.common.timing_alignment import TimingConfig, get_timing_manager, reset_timing_manager
+    from dart_planner_amd.common.types import DroneState
+    from dart_planner_amd.perception.explicit_geometric_mapper import ExplicitGeometricMapper
+    from dart_planner_amd.planning.se3_mpc_planner import SE3MPCConfig, SE3MPCPlanner
+    reset_timing_manager()
+    try:
+        get_timing_manager(TimingConfig(control_frequency=10.0))
+        pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=30), device="cuda:0")
+        assert abs(pl.se3_config.dt - 0.1) < 1e-12
+        mapper = ExplicitGeometricMapper(resolution=0.5, max_range=20.0, ops=gpu_ops)
+        mapper.add_obstacle(np.array([3.0, 0.0, 2.0]), 1.0)
+        st = DroneState(timestamp=0.0, position=np.array([0.0, 0.0, 2.0]), velocity=np.zeros(3))
+        goal = np.array([8.0, 0.5, 2.0])                       # 5 m behind the obstacle's centre: outside every sphere's margin (1 m voxels' spheres + 1.5 m)
+        spheres = mapper.local_obstacle_spheres(st.position, 20.0, 0.6, 20, 1.0)
+        assert len(spheres) >= 1
+        pl.clear_obstacles()
+        for c in spheres:
+            pl.add_obstacle(c[:3], float(c[3]))
+        kw = dict(n_samples=2048, iters=40, step=1e-3, sigma=2.0, seed=0, precision="f32")
+        blind = pl.plan_shooting(st, goal, obstacles=False, **kw)
+        assert "penalty" not in pl.last_result
+        aware = pl.plan_shooting(st, goal, **kw)                       # default: the planner's own obstacle list
+        res = dict(pl.last_result)
+        safe_blind, first_blind = mapper.is_trajectory_safe(blind.positions, safety_margin=1.0)
+        safe_aware, _ = mapper.is_trajectory_safe(aware.positions, safety_margin=1.0)
+        dmin = lambda tr: float(np.min(np.linalg.norm(np.asarray(tr.positions) - np.array([3.0, 0.0, 2.0]), axis=1)))
+        print(f"blind plan: safe={safe_blind} (first unsafe step {first_blind}), closest approach {dmin(blind):.2f} m; "
+              f"obstacle-aware plan: safe={safe_aware}, closest approach {dmin(aware):.2f} m, remaining penalty {res['penalty']:.3g}, "
+              f"{len(spheres)} spheres from the map")
+        assert not safe_blind and safe_aware
+        assert dmin(aware) > dmin(blind) + 1.0
+        assert np.linalg.norm(np.asarray(aware.positions)[-1] - goal) < 2.0          # it still gets there
+        # the eager (multi-rank) path gives the same plan as the captured one
+        from dart_planner_amd.distributed import sharded_shooting_plan
+        sph = pl._obstacle_table(None)
+        e = sharded_shooting_plan(gpu_ops, pl._params(), st.position, st.velocity, goal, kw["n_samples"], kw["iters"], kw["step"], kw["sigma"], kw["seed"],
+                                  "f32", spheres=sph, obstacle_weight=pl.se3_config.obstacle_weight)
+        assert e["sample"] == res["sample"] and np.array_equal(e["T"], res["T"])
+    finally:
+        reset_timing_manager()
+
+
 def test_planner_shooting_plan_shapes(gpu_ops):
     """The captured plan_shooting over odd sample counts (1, not a multiple of 64, one more than a multiple), zero iterations, both precisions and
     three horizons: the same winner and thrust sequence as the eager chain of the same launches; at most four captured graphs are kept."""
