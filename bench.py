@@ -802,13 +802,27 @@ def closed_loop_leg(torch, ops, dev):
             torch.cuda.synchronize()
             tg.append(time.perf_counter() - t0)
         eg = float(np.median(tg))
-        res[name] = {"wall_ms_per_monte_carlo": el * 1e3, "runs_per_s": S / el, "plans_per_s": S * cycles / el,
+        # the same Monte-Carlo in ONE launch (se3mpc_monte_carlo_*: same code, same bits; no kernel boundary at which all drones wait for the slowest)
+        def run1():
+            return mc.run_fused(p0, v0, goal, cycles, substeps, sim_dt, wind=wind)["pos"]
+        pos1 = run1(); torch.cuda.synchronize()
+        t1 = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            pos1 = run1()
+            torch.cuda.synchronize()
+            t1.append(time.perf_counter() - t0)
+        e1 = float(np.median(t1))
+        res[name] = {"one_launch_wall_ms_per_monte_carlo": e1 * 1e3, "one_launch_runs_per_s": S / e1, "one_launch_plans_per_s": S * cycles / e1,
+                     "one_launch_control_steps_per_s": S * cycles * substeps / e1, "one_launch_equals_two_launch_form": bool(torch.equal(pos1, pos)),
+                     "wall_ms_per_monte_carlo": el * 1e3, "runs_per_s": S / el, "plans_per_s": S * cycles / el,
                      "control_steps_per_s": S * cycles * substeps / el, "finite": bool(torch.isfinite(pos).all()),
                      "hipgraph_wall_ms_per_monte_carlo": eg * 1e3, "hipgraph_runs_per_s": S / eg,
                      "hipgraph_equals_eager": bool(torch.equal(outg["pos"], pos))}
         del replay
     return {"what": f"{S} closed-loop runs x {cycles} planning cycles x {substeps} control+simulator steps (horizon-6 plans, DI defaults), "
-                    "2 launches per cycle, no host arithmetic", **res}
+                    "2 launches per cycle (wall_ms_per_monte_carlo, hipgraph_*) or the whole run in ONE launch (one_launch_*), no host arithmetic", **res}
 
 
 def sweep(torch, ops, prm, dev, N):

@@ -200,6 +200,7 @@ _LOOP_TYPED_API = {
     "simulator_step": [_SP, _I, _D, _P, _P, _P, _LL, _P, _P, _P, _P, _P, _P],
     "closed_loop": [_CP, _SP, _I, _I, _D, _I, _P, _LL, _P, _LL, _P, _LL, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _LL, _I,
                     C.POINTER(C.c_double * 3), _I, _P, _P, _P, _P, _P],
+    "monte_carlo": [_PP, _CP, _SP, _I, _I, _I, _D, _P, _P, _LL, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
 _PLAIN_API = {
     "se3mpc_controller_default_params": (C.c_int, [_CP]),
@@ -345,11 +346,11 @@ class Library:
 
     def loop_call(self, base: str, suffix: str, *args) -> None:
         """se3mpc_control_<suffix> / se3mpc_closed_loop_<suffix>; struct arguments are passed by reference here."""
-        a = [C.byref(x) if isinstance(x, (ControllerParams, SimulatorParams)) else x for x in args]
+        a = [C.byref(x) if isinstance(x, (ControllerParams, SimulatorParams, Params)) else x for x in args]
         self._check(f"se3mpc_{base}_{suffix}", getattr(self._dll, f"se3mpc_{base}_{suffix}")(*a))
 
     def loop_status(self, base: str, suffix: str, *args) -> int:
-        a = [C.byref(x) if isinstance(x, (ControllerParams, SimulatorParams)) else x for x in args]
+        a = [C.byref(x) if isinstance(x, (ControllerParams, SimulatorParams, Params)) else x for x in args]
         return getattr(self._dll, f"se3mpc_{base}_{suffix}")(*a)
 
     # -- voxel map ----------------------------------------------------------------------------

@@ -47,6 +47,25 @@ class ClosedLoopMonteCarlo:
                 logs.append((sol, out))
         return dict(pos=pos, vel=vel, att=att, omega=om, time=time, controller_state=st, logs=logs)
 
+    def run_fused(self, p0, v0, goal, cycles: int, substeps: int, sim_dt: float, wind=None, want_last_plan: bool = False):
+        """The same Monte-Carlo in ONE launch (``se3mpc_monte_carlo_*``: every cycle's solve and control / simulator steps inside one kernel,
+        each drone paying only for its own slow solves instead of waiting, 2 x `cycles` times, at a kernel boundary for the slowest drone of
+        the batch).  Same code, same bits as :meth:`run`.  One host synchronise at the end reads the overflow counter; if a solve needed more
+        L-BFGS memory than the launch's LDS image holds (never with the reference's options) the run is repeated by :meth:`run`."""
+        import torch
+        ops = self.ops
+        dev = ops.be.device
+        B = p0.shape[0]
+        pos, vel = p0.clone(), v0.clone()
+        att, om = torch.zeros_like(p0), torch.zeros_like(p0)
+        time = torch.zeros(B, dtype=torch.float64, device=dev)
+        st = ops.controller_state(self.controller, B)
+        out = ops.monte_carlo(self.params, self.controller, self.simulator, st, time, pos, vel, att, om, goal, cycles, substeps, sim_dt, wind=wind,
+                              want_last_plan=want_last_plan)
+        if int(ops.be.to_host(out["overflowed"])[0]) != 0:
+            return self.run(p0, v0, goal, cycles, substeps, sim_dt, wind=wind)
+        return dict(pos=pos, vel=vel, att=att, omega=om, time=time, controller_state=st, logs=[], last_plan=out if want_last_plan else None)
+
     def capture(self, B: int, dtype, cycles: int, substeps: int, sim_dt: float, with_wind: bool = True):
         """The whole Monte-Carlo (2 x `cycles` kernel launches + the plan stamps) captured ONCE into a hipGraph; each call of the
         returned function copies new initial conditions into the graph's static inputs, replays it and returns the static outputs

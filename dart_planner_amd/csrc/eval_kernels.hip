@@ -98,7 +98,10 @@ init_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __
 // are ALL issued before the first use (3 * kChunk independent HBM requests in flight per lane, the same memory-level parallelism the
 // benchmarked rollout kernel gets from its register arrays), then consumed and stored.  Per-row loops with a load -> use -> store
 // dependence per step reached 55-63 % of the HBM peak; this shape reaches the copy ceiling of the part.
-constexpr int kChunk = 16;
+#ifndef SE3MPC_LANE_CHUNK
+#define SE3MPC_LANE_CHUNK 16
+#endif
+constexpr int kChunk = SE3MPC_LANE_CHUNK;
 
 template <typename R, bool WANT_G>
 __global__ void __launch_bounds__(192)

@@ -489,6 +489,35 @@ class Ops:
                            self.be.stream())
         return dict(thrust=thrust, torque=torque, flags=flags)
 
+    def monte_carlo(self, params: Params, cp: ControllerParams, sp: SimulatorParams, state, time, pos, vel, att, omega, goal, cycles: int,
+                    substeps: int, sim_dt: float, wind=None, want_last_plan: bool = False):
+        """se3mpc_monte_carlo_*: `cycles` x (solve from the drone's own state, `substeps` control + simulator steps against the fresh plan) for B
+        drones in ONE launch, in place on (state, time, pos, vel, att, omega).  -> dict(overflowed: int32 (1,) device array -- not 0 means
+        a solve needed more L-BFGS pairs than the launch's LDS image holds and the run must be repeated with solve + closed_loop launches;
+        x, accelerations, info of the last cycle's plan if asked for)."""
+        B = pos.shape[0]
+        suf = self.be.suffix(pos)
+        for a, nm in ((pos, "pos"), (vel, "vel"), (att, "att"), (omega, "omega"), (goal, "goal")):
+            self._rows3(a, B, nm, suf)
+        self.be.check(state, "state"); self.be.check(time, "time")
+        if tuple(state.shape) != (B, CONTROLLER_STATE_WORDS) or self.be.suffix(state) != "f64" or tuple(time.shape) != (B,) or self.be.suffix(time) != "f64":
+            raise ValueError("state: float64 (B, 12); time: float64 (B,)")
+        w_stride = 0
+        if wind is not None:
+            self.be.check(wind, "wind")
+            if self.be.suffix(wind) != suf or wind.shape[-1] != 3 or (wind.ndim == 2 and wind.shape[0] != B):
+                raise ValueError("wind: (3,) or (B, 3)")
+            w_stride = 3 if wind.ndim == 2 else 0
+        N = params.horizon
+        over = self.be.empty((1,), "i32")
+        X = self.be.empty((B, 9 * N), suf) if want_last_plan else None
+        acc = self.be.empty((B, N, 3), suf) if want_last_plan else None
+        info = self.be.empty((B * INFO_DTYPE.itemsize,), "u8") if want_last_plan else None
+        self.lib.loop_call("monte_carlo", suf, params, cp, sp, B, int(cycles), int(substeps), float(sim_dt), self.be.ptr(goal), self.be.ptr(wind), w_stride,
+                           self.be.ptr(time), self.be.ptr(pos), self.be.ptr(vel), self.be.ptr(att), self.be.ptr(omega), self.be.ptr(state),
+                           self.be.ptr(X), self.be.ptr(acc), self.be.ptr(info), self.be.ptr(over), self.be.stream())
+        return dict(overflowed=over, x=X, accelerations=acc, info=info)
+
     def controller_integral_update(self, cp: ControllerParams, state, vel_error, dt: float, saturation=None) -> None:
         """_update_integral_error(vel_error, dt, thrust_saturated, torque_saturated) (controller.py:536-564) for B drones, in place on
         `state`.  saturation: int32 (B,) bit 0 thrust, bits 1..3 torque x/y/z, or None."""

@@ -544,6 +544,25 @@ int se3mpc_closed_loop_f64(const se3mpc_controller_params* cp, const se3mpc_simu
                            const double* gust_wind, int stop_at_plan_end, double* log_state, double* log_cmd, double* log_time,
                            int32_t* steps_taken, void* stream);
 
+/* The receding-horizon closed-loop Monte-Carlo of BASELINE config 5's named test shape (tests/test_monte_carlo_sim.py:24-72) in ONE
+ * launch: for each of B drones, `cycles` times { se3mpc_solve_* from the drone's own (pos, vel) with the reference's cold start;
+ * `substeps` x se3mpc_closed_loop_*'s step (plan sample -> compute_control -> DroneSimulator.step at sim_dt) against the fresh plan,
+ * whose row k is stamped (cycle * substeps * sim_dt) + k * params->dt }.  The same code as the two entry points it fuses, hence the
+ * same bits as alternating them (dart_planner_amd/control/closed_loop.py) -- without 2 x cycles kernel boundaries at each of which every
+ * drone waits for the slowest one.  goal [B][3]; wind NULL or rows of wind_stride (0 = one shared row); time [B], pos / vel / att /
+ * omega [B][3], state [B][SE3MPC_CONTROLLER_STATE_WORDS]: in / out as se3mpc_closed_loop_*; X_last [B][9N], acc_last [B][3N],
+ * info_last [B] (each may be NULL): the last cycle's plan; overflowed: device int32, set to the number of solves that needed more
+ * L-BFGS pairs than this launch's LDS image holds (never with the reference's options) -- when it is not 0 the run must be repeated
+ * with the two-launch form. */
+int se3mpc_monte_carlo_f32(const se3mpc_params* p, const se3mpc_controller_params* cp, const se3mpc_simulator_params* sp, int B, int cycles,
+                           int substeps, double sim_dt, const float* goal, const float* wind, long long wind_stride, double* time,
+                           float* pos, float* vel, float* att, float* omega, double* state, float* X_last, float* acc_last,
+                           se3mpc_solve_info* info_last, int32_t* overflowed, void* stream);
+int se3mpc_monte_carlo_f64(const se3mpc_params* p, const se3mpc_controller_params* cp, const se3mpc_simulator_params* sp, int B, int cycles,
+                           int substeps, double sim_dt, const double* goal, const double* wind, long long wind_stride, double* time,
+                           double* pos, double* vel, double* att, double* omega, double* state, double* X_last, double* acc_last,
+                           se3mpc_solve_info* info_last, int32_t* overflowed, void* stream);
+
 /* ------------------------------------------------------------------ problem layout: [b][row]
  * The batched solve: replaces _solve_se3_mpc (planner.py:230-280) = cold start (or a caller
  * x0), box, scipy.optimize.minimize(method="L-BFGS-B", jac=..., bounds=..., maxiter, gtol,

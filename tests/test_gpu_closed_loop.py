@@ -390,6 +390,33 @@ def test_device_plan_travels_in_the_reference_envelope(gpu_ops):
     assert np.array_equal(trajectory_from_wire(ser.deserialize(raw)["trajectory"]).positions, tr.positions)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_monte_carlo_in_one_launch_equals_the_two_launch_form(gpu_ops, prec):
+    """se3mpc_monte_carlo_*: every planning cycle of every drone inside ONE kernel (each drone pays only for its own slow solves) ==
+    alternating se3mpc_solve_* and se3mpc_closed_loop_* (ClosedLoopMonteCarlo.run), BIT FOR BIT -- it is the same code: BASELINE config 5's
+    named shape (4096 runs x 33 cycles x 15 steps), a ragged batch at another horizon, shared / no wind."""
+    import torch
+    from dart_planner_amd.capi import Params
+    from dart_planner_amd.control.closed_loop import ClosedLoopMonteCarlo
+    dtype = torch.float32 if prec == "f32" else torch.float64
+    dev = gpu_ops.be.device
+    for N, B, cycles, substeps in ((6, 4096, 33, 15), (13, 77, 6, 7), (30, 131, 5, 4)):
+        mc = ClosedLoopMonteCarlo(gpu_ops, Params.reference_defaults(horizon=N))
+        g = torch.Generator(device=dev); g.manual_seed(5)
+        p0 = torch.tensor([0.0, 0.0, 2.0], dtype=dtype, device=dev).repeat(B, 1) + 0.2 * torch.randn(B, 3, dtype=dtype, device=dev, generator=g)
+        v0 = 0.3 * torch.randn(B, 3, dtype=dtype, device=dev, generator=g)
+        goal = torch.tensor([8.0, 0.0, 5.0], dtype=dtype, device=dev).repeat(B, 1).contiguous()
+        wind = torch.randn(B, 3, dtype=dtype, device=dev, generator=g).contiguous()
+        for w in (wind, None, wind[0].contiguous()):
+            a = mc.run(p0, v0, goal, cycles, substeps, 0.01, wind=w)
+            b = mc.run_fused(p0, v0, goal, cycles, substeps, 0.01, wind=w, want_last_plan=True)
+            for key in ("pos", "vel", "att", "omega", "time", "controller_state"):
+                assert torch.equal(a[key], b[key]), (N, B, key)
+            assert torch.isfinite(b["pos"]).all() and float((b["pos"] - p0).abs().max()) > 1e-3
+        info = gpu_ops.info_to_host(b["last_plan"]["info"])
+        assert set(np.unique(info["status"])) <= {0, 1, 2} and info["nit"].min() >= 1
+
+
 def test_monte_carlo_hipgraph_replay_equals_eager(gpu_ops):
     """The library never allocates or synchronises, so the whole receding-horizon Monte-Carlo (66 launches) captures into one hipGraph;
     a replay with new initial conditions equals the eager run bit for bit."""

@@ -1,6 +1,6 @@
 // Developer probe (GPU box): what limits write-heavy lane-layout streams?  [rows][B] float matrix, one column per lane;
 // a wavefront writes (or copies) RW consecutive rows of its 64 columns; grid = (column blocks, row chunks).
-// Usage: probe_rows [rows=270] [log2B=20]
+// Usage: probe_rows [rows=270] [log2B=20] [ld_pad=0]      (leading dimension = B + ld_pad columns: does the 4 MB row stride of B = 1 M alias channels / pages?)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -42,18 +42,20 @@ __global__ void __launch_bounds__(64) rows4_kernel(const vf4* __restrict__ src, 
 int main(int argc, char** argv) {
   const int rows = argc > 1 ? atoi(argv[1]) : 270;
   const size_t B = (size_t)1 << (argc > 2 ? atoi(argv[2]) : 20);
+  const size_t LD = B + (size_t)(argc > 3 ? atoi(argv[3]) : 0);
   float *src, *dst, *sink;
-  hipMalloc(&src, rows * B * 4); hipMalloc(&dst, rows * B * 4); hipMalloc(&sink, 4);
-  hipMemset(src, 0, rows * B * 4);
+  hipMalloc(&src, rows * LD * 4); hipMalloc(&dst, rows * LD * 4); hipMalloc(&sink, 4);
+  hipMemset(src, 0, rows * LD * 4);
+  printf("rows %d  B %zu  ld %zu (row stride %zu bytes)\n", rows, B, LD, LD * 4);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const char* names[] = {"write", "copy", "read"};
   for (int mode = 0; mode < 3; ++mode)
-    for (int rw : {rows, 90, 30, 10, 3, 1}) {
+    for (int rw : {rows, 30, 10}) {
       dim3 grid(B / 64, (rows + rw - 1) / rw);
       auto launch = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(rows_kernel<0>, grid, dim3(64), 0, 0, src, dst, rows, B, rw, sink);
-        else if (mode == 1) hipLaunchKernelGGL(rows_kernel<1>, grid, dim3(64), 0, 0, src, dst, rows, B, rw, sink);
-        else hipLaunchKernelGGL(rows_kernel<2>, grid, dim3(64), 0, 0, src, dst, rows, B, rw, sink);
+        if (mode == 0) hipLaunchKernelGGL(rows_kernel<0>, grid, dim3(64), 0, 0, src, dst, rows, LD, rw, sink);
+        else if (mode == 1) hipLaunchKernelGGL(rows_kernel<1>, grid, dim3(64), 0, 0, src, dst, rows, LD, rw, sink);
+        else hipLaunchKernelGGL(rows_kernel<2>, grid, dim3(64), 0, 0, src, dst, rows, LD, rw, sink);
       };
       for (int i = 0; i < 2; ++i) launch();
       hipEventRecord(e0);
@@ -67,9 +69,9 @@ int main(int argc, char** argv) {
     for (int rw : {rows, 30, 10}) {
       dim3 grid(B / 256, (rows + rw - 1) / rw);
       auto launch = [&]() {
-        if (mode == 0) hipLaunchKernelGGL(rows4_kernel<0>, grid, dim3(64), 0, 0, (const vf4*)src, (vf4*)dst, rows, B / 4, rw, sink);
-        else if (mode == 1) hipLaunchKernelGGL(rows4_kernel<1>, grid, dim3(64), 0, 0, (const vf4*)src, (vf4*)dst, rows, B / 4, rw, sink);
-        else hipLaunchKernelGGL(rows4_kernel<2>, grid, dim3(64), 0, 0, (const vf4*)src, (vf4*)dst, rows, B / 4, rw, sink);
+        if (mode == 0) hipLaunchKernelGGL(rows4_kernel<0>, grid, dim3(64), 0, 0, (const vf4*)src, (vf4*)dst, rows, LD / 4, rw, sink);
+        else if (mode == 1) hipLaunchKernelGGL(rows4_kernel<1>, grid, dim3(64), 0, 0, (const vf4*)src, (vf4*)dst, rows, LD / 4, rw, sink);
+        else hipLaunchKernelGGL(rows4_kernel<2>, grid, dim3(64), 0, 0, (const vf4*)src, (vf4*)dst, rows, LD / 4, rw, sink);
       };
       for (int i = 0; i < 2; ++i) launch();
       hipEventRecord(e0);
