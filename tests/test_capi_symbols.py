@@ -87,3 +87,31 @@ def test_header_is_plain_c(tmp_path):
                    '  (void)p; (void)m; (void)i; return se3mpc_abi_version() == SE3MPC_ABI_VERSION ? 0 : 1; }\n')
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
                     str(src)], check=True)
+
+
+def test_solver_kernels_do_not_spill():
+    """The packed solver kernels (solve_kernel<float|double, 8|16|32|64>) are compiled for two wavefronts per SIMD (256 registers) and must
+    need neither spilled vector registers nor scratch memory: spill code inside the divergent control flow of co-resident problems is
+    what DESIGN.md section 5.2 rules out instead of reasoning about it.  Read from the ISA metadata of a device-only `hipcc -S`."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc) and shutil.which("hipcc") is None:
+        pytest.skip("no hipcc on this machine")
+    src = os.path.join(ROOT, "dart_planner_amd", "csrc", "solve_kernel.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "solve_kernel.s")
+        subprocess.run([hipcc if os.path.exists(hipcc) else "hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"),
+                        "-I" + os.path.join(ROOT, "dart_planner_amd", "csrc"), "-fno-gpu-rdc", "-fno-slp-vectorize", "--cuda-device-only", "-S", src, "-o", out],
+                       check=True, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+        text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):]
+    kernels = [blk for blk in meta.split("  - .agpr_count:")[1:] if "solve_kernel" in blk]
+    assert len(kernels) == 8, len(kernels)
+    for blk in kernels:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        get = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+        assert get("vgpr_spill_count") == 0 and get("private_segment_fixed_size") == 0, (name, get("vgpr_spill_count"), get("private_segment_fixed_size"))
+        assert get("vgpr_count") <= 256 and int(blk.split("\n")[0].strip()) == 0, (name, get("vgpr_count"))     # two wavefronts per SIMD, no AGPRs

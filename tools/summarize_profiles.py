@@ -51,15 +51,17 @@ out = {"rollout_fused_64x8192_graph": durations(tr, 64), "rollout_single_8192_gr
        "solve_kernel_single_problem": None, "solve_kernel_batch_8192": None}
 sv = rows_of("solve", "solve_kernel")
 if sv:
-    # up to 1024 problems a solve is ONE launch (full L-BFGS memory in LDS); larger batches are two back-to-back
-    # launches: tier 1 (LDS for 4 pairs, all problems) and tier 2 (full LDS, every wavefront but the overflowed ones
-    # exits at once) -- alternate dispatches of the same grid.  The single-problem group holds the f64 and the f32 legs.
+    # the packed solver: 64 / G problems per wavefront (G = 32 lanes per problem at horizon 30; a lone problem takes a whole wavefront).  A
+    # launch whose wavefronts cannot all be resident with the full L-BFGS memory in LDS is two back-to-back launches: tier 1 (LDS for 2-4
+    # pairs, all problems) and tier 2 (full LDS, every group but the overflowed ones exits at once) -- alternate dispatches of the same grid.
     single = sorted((r for r in sv if int(r["Grid_Size_X"]) == 64), key=lambda r: int(r["Dispatch_Id"]))
     out["solve_kernel_single_problem_f64"] = durations([r for r in single if "<double" in r["Kernel_Name"]])
     out["solve_kernel_single_problem_f32"] = durations([r for r in single if "<float" in r["Kernel_Name"]])
-    grp = sorted((r for r in sv if int(r["Grid_Size_X"]) == 64 * B), key=lambda r: int(r["Dispatch_Id"]))
+    grp = sorted((r for r in sv if int(r["Grid_Size_X"]) == 32 * B), key=lambda r: int(r["Dispatch_Id"]))
     out["solve_kernel_batch_8192_tier1"] = durations(grp[0::2])
     out["solve_kernel_batch_8192_tier2_empty"] = durations(grp[1::2])
+    out["solve_kernel_registers"] = {"VGPR_Count": grp[0].get("VGPR_Count"), "Accum_VGPR_Count": grp[0].get("Accum_VGPR_Count"), "Scratch_Size": grp[0].get("Scratch_Size"),
+                                     "LDS_Block_Size_tier1": grp[0].get("LDS_Block_Size")} if grp else None
     del out["solve_kernel_single_problem"], out["solve_kernel_batch_8192"]
 for tag, rollouts, gy in (("fused", 64 * B, 64), ("single", B, None), ("b4m", 4194304, None)):
     alg_r = 4 * (3 * N + 9) * rollouts
@@ -95,6 +97,10 @@ for name, needle, gy in (("cfg2_single_1024", "rollout_kernel", 1), ("cfg2_batch
                          ("cfg3_single_8192", "rollout_obstacles_kernel", 1), ("cfg3_batched_64x8192", "rollout_obstacles_kernel", 64)):
     cf[name] = durations(rows_of("configs", needle), gy)
 out["configs"] = cf
+lsv = sorted((r for r in rows_of("loop", "solve_kernel") if int(r["Grid_Size_X"]) == 8 * 4096), key=lambda r: int(r["Dispatch_Id"]))
 out["closed_loop"] = {"closed_loop_kernel_4096x15": durations(rows_of("loop", "closed_loop_kernel")),
-                      "solve_kernel_4096_h6": durations([r for r in rows_of("loop", "solve_kernel") if int(r["Grid_Size_X"]) == 64 * 4096][0::2])}
+                      "solve_kernel_4096_h6_tier1": durations(lsv[0::2]), "solve_kernel_4096_h6_tier2_empty": durations(lsv[1::2]),
+                      "monte_carlo_kernel_4096x33x15_f32": durations([r for r in rows_of("loop", "monte_carlo_kernel") if "<float" in r["Kernel_Name"]]),
+                      "monte_carlo_kernel_4096x33x15_f64": durations([r for r in rows_of("loop", "monte_carlo_kernel") if "<double" in r["Kernel_Name"]])}
+out["rollout_iterate_obstacles_cfg3"] = durations(rows_of("iter_16", "rollout_iterate_obstacles_kernel"))
 print(json.dumps(out, indent=1))
