@@ -502,15 +502,18 @@ __device__ __forceinline__ uint32_t orderable_bits(float c) {
 // 2.8x on a 64-batch launch; se3mpc_reduce_keys folds the slots afterwards, once per bucket.
 // Tail lanes (b >= B) stay active up to here so the cross-lane ops see all 64 lanes; they contribute
 // the identity.
-template <typename R>
+template <typename R, bool SHARED_SLOT = false>
 __device__ __forceinline__ void rollout_epilogue(bool live, int b, R c, R* __restrict__ cost,
                                                  unsigned long long* __restrict__ wave_key_slot, uint32_t index_base) {
   if (live) cost[b] = c;
   const uint32_t bits = live ? orderable_bits((float)c) : 0xFFFFFFFFu;
   const uint32_t m = wave_min_u32(bits);
   const int src = first_lane(wave_ballot(live && bits == m));
-  if (wave_key_slot != nullptr && src >= 0 && lane_id() == src)
-    *wave_key_slot = ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b);
+  if (wave_key_slot != nullptr && src >= 0 && lane_id() == src) {
+    const unsigned long long k = ((unsigned long long)m << 32) | (unsigned long long)(index_base + (uint32_t)b);
+    if constexpr (SHARED_SLOT) atomicMin(wave_key_slot, k);   // several workgroups per slot (preset to ~0 by the launcher); min is order-free
+    else *wave_key_slot = k;
+  }
 }
 
 template <typename R>
@@ -758,32 +761,53 @@ struct ObsCtx {
   R* pen;             // [W][64]: each wavefront's share of the penalty, last pass
   R* pen_first;       // [W][64]: the same at the first pass (cost at T_in)
   int Kpad, W;
+  bool axis_sweeps;   // false: the axis wavefronts only meet the barriers, the helpers (wavefronts 3 .. W-1) take every step between them
+  int slot, slots;    // this lane's share of the steps: k = slot, slot + slots, ...  (TS = 32 trajectories per workgroup: a wavefront's two
+                      // halves take different steps of the same 32 trajectories)
   R w_obs;
 };
 
-// steps k = w, w + W, ... of every lane's trajectory: tile holds P_k on entry and dpenalty/dP_k on exit; returns this wavefront's
-// share of the penalty (already weighted)
-template <typename R>
-__device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int w, int W, int lane,
+// Two spheres against one position, both sweeps (table in LDS / table in registers) through this one expression so that they agree bit for bit.
+typedef float obs_f2 __attribute__((vector_size(8)));
+// PEN = false (descent passes, whose penalty nobody reads): the gradient only.
+template <bool PEN = true>
+__device__ __forceinline__ void sphere_pair(obs_f2 px2, obs_f2 py2, obs_f2 pz2, obs_f2 cx, obs_f2 cy, obs_f2 cz, obs_f2 r2, obs_f2& pk, obs_f2& qx,
+                                            obs_f2& qy, obs_f2& qz) {
+  const obs_f2 dx = px2 - cx, dy = py2 - cy, dz = pz2 - cz;
+  const obs_f2 c = dz * dz + (dy * dy + (dx * dx - r2));        // three fused multiply-adds (a padding row's r2 = -inf gives c = +inf, h = 0)
+  const obs_f2 h = obs_f2{fmaxf(0.0f, -c[0]), fmaxf(0.0f, -c[1])};
+  if constexpr (PEN) pk += h * h;
+  qx += h * dx; qy += h * dy; qz += h * dz;
+}
+template <typename R, bool PEN = true>
+__device__ __forceinline__ void sphere_one(R px, R py, R pz, R cx, R cy, R cz, R r2, R& pk, R& qx, R& qy, R& qz) {
+  const R dx = px - cx, dy = py - cy, dz = pz - cz;
+  const R c = dz * dz + (dy * dy + (dx * dx - r2));
+  const R h = fmax((R)0, -c);
+  if constexpr (PEN) pk += h * h;
+  qx += h * dx; qy += h * dy; qz += h * dz;
+}
+
+// steps k = first, first + stride, ... of every lane's trajectory: tile holds P_k on entry and dpenalty/dP_k on exit; returns this
+// wavefront's share of the penalty (already weighted)
+template <typename R, int TS>
+__device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int first, int stride, int lane,
                                                     R w_obs) {
   R pen = (R)0;
   const R scale = (R)-4 * w_obs;
-  for (int k = w; k < Nn; k += W) {
+  lane &= TS - 1;
+  for (int k = first; k < Nn; k += stride) {
     R* tx = tile + ((size_t)0 * Nn + k) * kWave + lane;
     R* ty = tile + ((size_t)1 * Nn + k) * kWave + lane;
     R* tz = tile + ((size_t)2 * Nn + k) * kWave + lane;
     const R px = *tx, py = *ty, pz = *tz;
     if constexpr (sizeof(R) == 4) {
-      typedef float f2 __attribute__((vector_size(8)));
-      const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz}, zero = {0.0f, 0.0f};
-      f2 qx = zero, qy = zero, qz = zero, pk = zero;
+      const obs_f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz}, zero = {0.0f, 0.0f};
+      obs_f2 qx = zero, qy = zero, qz = zero, pk = zero;
 #pragma unroll 4
       for (int j = 0; j < Kpad; j += 2) {                      // two spheres per packed instruction (Kpad is a multiple of 8)
         const R* s0 = sph + 4 * j;
-        const f2 dx = px2 - f2{s0[0], s0[4]}, dy = py2 - f2{s0[1], s0[5]}, dz = pz2 - f2{s0[2], s0[6]};
-        const f2 c = (dx * dx + dy * dy + dz * dz) - f2{s0[3], s0[7]};
-        const f2 h = f2{fmaxf(0.0f, -c[0]), fmaxf(0.0f, -c[1])};
-        pk += h * h; qx += h * dx; qy += h * dy; qz += h * dz;
+        sphere_pair(px2, py2, pz2, obs_f2{s0[0], s0[4]}, obs_f2{s0[1], s0[5]}, obs_f2{s0[2], s0[6]}, obs_f2{s0[3], s0[7]}, pk, qx, qy, qz);
       }
       pen += pk[0] + pk[1];
       *tx = scale * (qx[0] + qx[1]); *ty = scale * (qy[0] + qy[1]); *tz = scale * (qz[0] + qz[1]);
@@ -791,10 +815,7 @@ __device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const 
       R qx = (R)0, qy = (R)0, qz = (R)0, pk = (R)0;
       for (int j = 0; j < Kpad; ++j) {
         const R* s0 = sph + 4 * j;
-        const R dx = px - s0[0], dy = py - s0[1], dz = pz - s0[2];
-        const R c = (dx * dx + dy * dy + dz * dz) - s0[3];
-        const R h = fmax((R)0, -c);
-        pk += h * h; qx += h * dx; qy += h * dy; qz += h * dz;
+        sphere_one<R>(px, py, pz, s0[0], s0[1], s0[2], s0[3], pk, qx, qy, qz);
       }
       pen += pk;
       *tx = scale * qx; *ty = scale * qy; *tz = scale * qz;
@@ -803,18 +824,119 @@ __device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const 
   return w_obs * pen;
 }
 
+// The helpers' sweep: the 8 * KP spheres live in REGISTERS for the whole launch (a helper wavefront holds nothing else), so a step costs
+// its 6.5 VALU instructions per sphere and no LDS broadcast reads (with one wavefront per SIMD nothing hides their latency: measured
+// 1300 cycles per step with the table in LDS against 450 for the arithmetic); the next step's position is fetched under the current one's
+// arithmetic.  Same expression, same order as obstacle_penalty_sweep.
+template <typename R, int KP>
+struct SphereRegs {
+  static constexpr int kPairs = sizeof(R) == 4 ? 4 * KP : 1, kOnes = sizeof(R) == 4 ? 1 : 8 * KP;
+  obs_f2 cx2[kPairs], cy2[kPairs], cz2[kPairs], r22[kPairs];
+  R cx[kOnes], cy[kOnes], cz[kOnes], r2[kOnes];
+  __device__ __forceinline__ void load(const R* __restrict__ sph) {
+    if constexpr (sizeof(R) == 4) {
+#pragma unroll
+      for (int i = 0; i < kPairs; ++i) {
+        const R* s0 = sph + 8 * i;
+        cx2[i] = obs_f2{s0[0], s0[4]}; cy2[i] = obs_f2{s0[1], s0[5]}; cz2[i] = obs_f2{s0[2], s0[6]}; r22[i] = obs_f2{s0[3], s0[7]};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kOnes; ++i) { cx[i] = sph[4 * i]; cy[i] = sph[4 * i + 1]; cz[i] = sph[4 * i + 2]; r2[i] = sph[4 * i + 3]; }
+    }
+  }
+};
+
+template <typename R, int KP, int U, int TS, bool PEN>
+__device__ __forceinline__ R obstacle_penalty_sweep_regs(R* __restrict__ tile, const SphereRegs<R, KP>& sr, int Nn, int first, int stride, int lane,
+                                                         R w_obs) {
+  // U steps in flight: a packed float instruction's result is ready for a dependent one only ~8 cycles after issue, and a helper has its
+  // SIMD to itself -- the distance chains of U different steps interleave and fill those slots.
+  R pen = (R)0;
+  const R scale = (R)-4 * w_obs;
+  lane &= TS - 1;
+#pragma unroll 1
+  for (int k0 = first; k0 < Nn; k0 += U * stride) {
+    R px[U], py[U], pz[U];
+    R* tx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = k0 + u * stride;
+      tx[u] = tile + (size_t)(k < Nn ? k : k0) * kWave + lane;
+      px[u] = tx[u][0]; py[u] = tx[u][(size_t)Nn * kWave]; pz[u] = tx[u][(size_t)2 * Nn * kWave];
+    }
+    if constexpr (sizeof(R) == 4) {
+      const obs_f2 zero = {0.0f, 0.0f};
+      obs_f2 px2[U], py2[U], pz2[U], qx[U], qy[U], qz[U], pk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { px2[u] = obs_f2{px[u], px[u]}; py2[u] = obs_f2{py[u], py[u]}; pz2[u] = obs_f2{pz[u], pz[u]}; qx[u] = qy[u] = qz[u] = pk[u] = zero; }
+#pragma unroll
+      for (int i = 0; i < SphereRegs<R, KP>::kPairs; ++i) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) sphere_pair<PEN>(px2[u], py2[u], pz2[u], sr.cx2[i], sr.cy2[i], sr.cz2[i], sr.r22[i], pk[u], qx[u], qy[u], qz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (k0 + u * stride < Nn) {
+          pen += pk[u][0] + pk[u][1];
+          tx[u][0] = scale * (qx[u][0] + qx[u][1]); tx[u][(size_t)Nn * kWave] = scale * (qy[u][0] + qy[u][1]);
+          tx[u][(size_t)2 * Nn * kWave] = scale * (qz[u][0] + qz[u][1]);
+        }
+      }
+    } else {
+      R qx[U], qy[U], qz[U], pk[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) qx[u] = qy[u] = qz[u] = pk[u] = (R)0;
+#pragma unroll
+      for (int i = 0; i < SphereRegs<R, KP>::kOnes; ++i) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) sphere_one<R, PEN>(px[u], py[u], pz[u], sr.cx[i], sr.cy[i], sr.cz[i], sr.r2[i], pk[u], qx[u], qy[u], qz[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (k0 + u * stride < Nn) {
+          pen += pk[u];
+          tx[u][0] = scale * qx[u]; tx[u][(size_t)Nn * kWave] = scale * qy[u]; tx[u][(size_t)2 * Nn * kWave] = scale * qz[u];
+        }
+      }
+    }
+  }
+  return w_obs * pen;
+}
+
 // one exchange of an obstacle-aware pass, executed by EVERY wavefront of the workgroup (axis wavefronts from inside their sweeps,
 // the helper wavefronts from the kernel body): barrier, this wavefront's share of the sweep, barrier
-template <typename R>
+template <typename R, int TS = kWave>
 __device__ __forceinline__ void obstacle_exchange(const ObsCtx<R>& o, int Nn, int w, int lane, bool first) {
   __syncthreads();
-  const R pen = obstacle_penalty_sweep<R>(o.tile, o.sph, Nn, o.Kpad, w, o.W, lane, o.w_obs);
+  R pen = (R)0;
+  if (o.axis_sweeps || w >= 3) pen = obstacle_penalty_sweep<R, TS>(o.tile, o.sph, Nn, o.Kpad, o.slot, o.slots, lane, o.w_obs);
   o.pen[w * kWave + lane] = pen;
   if (first) o.pen_first[w * kWave + lane] = pen;
   __syncthreads();
 }
 
-template <typename R, int N, bool EXACT, int LDAUX, int STAUX, bool OBS = false>
+#ifndef SE3MPC_OBS_STEPS_IN_FLIGHT
+#define SE3MPC_OBS_STEPS_IN_FLIGHT 2
+#endif
+// the helpers' passes with the sphere table in registers
+template <typename R, int KP, int TS>
+__device__ __forceinline__ void helper_passes_regs(const ObsCtx<R>& o, int Nn, int w, int lane, int passes) {
+  SphereRegs<R, KP> sr;
+  sr.load(o.sph);
+#pragma unroll 1
+  for (int ps = 0; ps < passes; ++ps) {
+    __syncthreads();
+    R pen = (R)0;                                             // (only the first and the last pass' penalties are ever read)
+    if (ps == 0 || ps == passes - 1) pen = obstacle_penalty_sweep_regs<R, KP, SE3MPC_OBS_STEPS_IN_FLIGHT, TS, true>(o.tile, sr, Nn, o.slot, o.slots, lane, o.w_obs);
+    else (void)obstacle_penalty_sweep_regs<R, KP, SE3MPC_OBS_STEPS_IN_FLIGHT, TS, false>(o.tile, sr, Nn, o.slot, o.slots, lane, o.w_obs);
+    o.pen[w * kWave + lane] = pen;
+    if (ps == 0) o.pen_first[w * kWave + lane] = pen;
+    __syncthreads();
+  }
+}
+
+template <typename R, int N, bool EXACT, int LDAUX, int STAUX, bool OBS = false, int TS = kWave>
 __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
                                               R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, bool want_first,
@@ -861,7 +983,7 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
   bool first_exchange = true;
   if (want_first && iters > 0) {
     cost_first = forward_cost();
-    if constexpr (OBS) { obstacle_exchange<R>(*obs, Nn, a, lane_, first_exchange); first_exchange = false; }     // the penalty at T_in
+    if constexpr (OBS) { obstacle_exchange<R, TS>(*obs, Nn, a, lane_, first_exchange); first_exchange = false; }     // the penalty at T_in
   }
   // Descent iterations in their leanest algebraically equal form (11 VALU per step instead of 17): the position error e = P - goal is
   // rolled out directly (the goal is constant, so e obeys P's recurrence), the local part of the gradient is one fma
@@ -885,7 +1007,7 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
         v = fma_r(acc, q.dt, v);
       }
     }
-    if constexpr (OBS) { obstacle_exchange<R>(*obs, Nn, a, lane_, first_exchange); first_exchange = false; }
+    if constexpr (OBS) { obstacle_exchange<R, TS>(*obs, Nn, a, lane_, first_exchange); first_exchange = false; }
     R lamP = (R)0, lamV = (R)0;
 #pragma unroll
     for (int k = N - 1; k >= 0; --k) {                          // adjoint sweep; T_k is overwritten as soon as its gradient exists
@@ -907,7 +1029,7 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
   // the last evaluation: cost and gradient at the final T (the gradient parks in the state registers it has just consumed)
   const R cost = forward_cost();
   if (!(want_first && iters > 0)) cost_first = cost;
-  if constexpr (OBS) obstacle_exchange<R>(*obs, Nn, a, lane_, first_exchange);
+  if constexpr (OBS) obstacle_exchange<R, TS>(*obs, Nn, a, lane_, first_exchange);
   if (gradT != nullptr) {
     R lamP = (R)0, lamV = (R)0;
 #pragma unroll
@@ -949,7 +1071,7 @@ __device__ __forceinline__ R iterate_axis_reg(const DevParams<R>& q, int a, unsi
 
 // Any horizon: the working copy of T lives in Tout (the lane's own elements, L1/L2-resident between iterations); states are
 // recovered by walking the recurrence backwards as in rollout_axis_rev.
-template <typename R, bool OBS = false>
+template <typename R, bool OBS = false, int TS = kWave>
 __device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal, const R* __restrict__ Tin,
                                               R* __restrict__ Tout, R* __restrict__ gradT, int iters, R step, bool live, bool want_first,
@@ -995,7 +1117,7 @@ __device__ __forceinline__ R iterate_axis_mem(const DevParams<R>& q, int a, unsi
     s.sp += s.sterm;
     cost = axis_cost(q, s);
     if (it == 0) cost_first = cost;
-    if constexpr (OBS) obstacle_exchange<R>(*obs, N, a, lane_, it == 0);
+    if constexpr (OBS) obstacle_exchange<R, TS>(*obs, N, a, lane_, it == 0);
     R lamP = c.two_wp * ((R)1 + q.term) * (pl - c.gl);
     if constexpr (OBS) lamP += my_tile[(size_t)(N - 1) * kWave];
     R lamV = c.two_wv * vl;
@@ -1060,17 +1182,31 @@ rollout_iterate_kernel(DevParams<R> q, int B, int ld, int iters, R step, const R
   rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
 }
 
-// The obstacle-aware form of rollout_iterate_kernel (see ObsCtx above).  W wavefronts per workgroup: the three axis wavefronts, and
-// for W = 8 five helpers that only take their share of the distance evaluations (for batches that leave SIMDs idle the evaluations
-// are the critical path: 800 per trajectory and iteration at horizon 50 with 16 spheres against ~600 instructions of rollout).
+#ifndef SE3MPC_OBS_WIDE_W
+#define SE3MPC_OBS_WIDE_W 7
+#endif
+#ifndef SE3MPC_OBS_WIDE_TS
+#define SE3MPC_OBS_WIDE_TS 32
+#endif
+constexpr int kObsWideW = SE3MPC_OBS_WIDE_W, kObsWideTS = SE3MPC_OBS_WIDE_TS;
+// The obstacle-aware form of rollout_iterate_kernel (see ObsCtx above).  Two workgroup shapes:
+//   <W = 3, TS = 64>: the three axis wavefronts of 64 trajectories, each sweeping a third of the steps against the LDS-resident sphere
+//     table -- for launches with enough workgroups to keep every SIMD busy with several wavefronts (which hide the LDS latency);
+//   <W = 7, TS = 32>: for launches that would leave compute units idle (8192 trajectories = 128 workgroups of 64 on 256 CUs).  A workgroup
+//     takes 32 trajectories (twice the workgroups), its axis wavefronts only roll out / run the adjoint, and FOUR helper wavefronts -- one
+//     per SIMD of the CU: a fifth would share a SIMD and become the critical path, measured -- take all the distance evaluations with the
+//     sphere table in their registers; the two halves of a helper take different steps of the same 32 trajectories.
 // cost = running cost + penalty at T_out; penalty: NULL or [B] = the penalty alone (0 = the plan keeps the margin of every sphere).
-template <typename R, int N, bool REG, int FLAGS, int W>
+// key: one slot per 64 trajectories (the ABI's ceil(B/64)); with TS = 32 the two workgroups of a slot fold into it with atomicMin (the
+// launcher presets the slots to the dead-lane sentinel).
+template <typename R, int N, bool REG, int FLAGS, int W, int TS>
 __global__ void __launch_bounds__(64 * W)
 rollout_iterate_obstacles_kernel(DevParams<R> q, int B, int ld, int iters, R step, const R* __restrict__ p0, const R* __restrict__ v0,
                                  const R* __restrict__ goal, const R* __restrict__ Tin, R* __restrict__ Tout, R* __restrict__ cost_first,
                                  R* __restrict__ cost, R* __restrict__ gradT, const R* __restrict__ spheres, int K, R w_obs,
                                  R* __restrict__ penalty, unsigned long long* __restrict__ key, uint32_t index_base) {
   HIP_DYNAMIC_SHARED(unsigned char, lds_raw)
+  constexpr int SUBS = kWave / TS;                            // halves of a wavefront that share a trajectory set
   {
     const size_t bi = blockIdx.y, ss = (size_t)3 * ld, st = (size_t)3 * q.N * ld;
     p0 += bi * ss; v0 += bi * ss; Tin += bi * st; Tout += bi * st; cost += bi * (size_t)ld;
@@ -1078,14 +1214,15 @@ rollout_iterate_obstacles_kernel(DevParams<R> q, int B, int ld, int iters, R ste
     if (gradT != nullptr) gradT += bi * st;
     if (cost_first != nullptr) cost_first += bi * (size_t)ld;
     if (penalty != nullptr) penalty += bi * (size_t)ld;
-    if (key != nullptr) key += bi * (size_t)gridDim.x;
+    if (key != nullptr) key += bi * (size_t)((B + kWave - 1) / kWave);
   }
   const int Kpad = (K + 7) / 8 * 8;
-  R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]: positions, then dpenalty/dP, of the pass in flight
+  R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]: positions, then dpenalty/dP, of the pass in flight (TS = 32: the
+                                                             // shadow half of an axis wavefront keeps columns 32..63 to itself; nobody reads them)
   R* sph = tile + (size_t)3 * q.N * kWave;                   // [Kpad][4]
   R* pcost = sph + (size_t)4 * Kpad;                         // [3][64] axis costs at T_out, [3][64] at T_in
   R* ppen = pcost + 6 * kWave;                               // [W][64] penalty shares at T_out, [W][64] at T_in
-  for (int i = threadIdx.x; i < Kpad; i += 64 * W) {         // visible to every wavefront behind the first exchange's barrier
+  for (int i = threadIdx.x; i < Kpad; i += 64 * W) {         // visible to every wavefront behind the first barrier
     if (i < K) {
       const R sm = spheres[4 * i + 3] + q.margin;
       sph[4 * i + 0] = spheres[4 * i + 0]; sph[4 * i + 1] = spheres[4 * i + 1]; sph[4 * i + 2] = spheres[4 * i + 2]; sph[4 * i + 3] = sm * sm;
@@ -1096,35 +1233,57 @@ rollout_iterate_obstacles_kernel(DevParams<R> q, int B, int ld, int iters, R ste
   int blk = blockIdx.x;
   if ((FLAGS & 4) && (gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
   const int lane = threadIdx.x & (kWave - 1);
-  const int b0 = blk * kWave + lane;
-  const bool live = b0 < B;
-  const int b = live ? b0 : B - 1;
+  const int tl = lane & (TS - 1), sub = lane / TS;
+  const int b0 = blk * TS + tl;
+  const bool live = b0 < B && sub == 0;                       // the second half of a TS = 32 axis wavefront shadows the first: same loads, no stores,
+                                                             // and nothing it computes is used (its tile columns never receive an obstacle gradient)
+  const int b = b0 < B ? b0 : B - 1;
   const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int a = wave_uniform((int)(threadIdx.x / kWave));
   ObsCtx<R> o;
   o.tile = tile; o.sph = sph; o.pen = ppen; o.pen_first = ppen + W * kWave; o.Kpad = Kpad; o.W = W; o.w_obs = w_obs;
+  // (no table, or one too long for the helpers' registers: everyone sweeps from LDS)
+  o.axis_sweeps = W <= 3 || Kpad == 0 || Kpad / 8 > (sizeof(R) == 4 ? 4 : 2);
+  if (o.axis_sweeps) { o.slot = a * SUBS + sub; o.slots = W * SUBS; }
+  else { o.slot = (a - 3) * SUBS + sub; o.slots = (W - 3) * SUBS; }       // (axis wavefronts never read theirs)
+  if constexpr (W > 3) __syncthreads();                       // the helpers read the table into registers before the first exchange
   if (a < 3) {
     R c0 = (R)0, c;
-    if constexpr (REG) c = iterate_axis_reg<R, N, !(FLAGS & 8), (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0, true>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0, &o);
-    else c = iterate_axis_mem<R, true>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0, &o);
+    if constexpr (REG) c = iterate_axis_reg<R, N, !(FLAGS & 8), (FLAGS & 1) ? 2 : 0, (FLAGS & 2) ? 2 : 0, true, TS>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0, &o);
+    else c = iterate_axis_mem<R, true, TS>(q, a, voff, rowb, p0, v0, goal, Tin, Tout, gradT, iters, step, live, cost_first != nullptr, c0, &o);
     pcost[a * kWave + lane] = c; pcost[(3 + a) * kWave + lane] = c0;
   } else {
     // as many exchanges as the axis wavefronts run: one per descent iteration, the last evaluation, and (register form) the
     // evaluation at T_in when its cost is asked for
     const int passes = iters + 1 + ((REG && cost_first != nullptr && iters > 0) ? 1 : 0);
-    for (int ps = 0; ps < passes; ++ps) obstacle_exchange<R>(o, q.N, a, lane, ps == 0);
+    const int kp = Kpad / 8;
+    if (o.axis_sweeps) {
+      for (int ps = 0; ps < passes; ++ps) obstacle_exchange<R, TS>(o, q.N, a, lane, ps == 0);
+    } else if (kp == 1) helper_passes_regs<R, 1, TS>(o, q.N, a, lane, passes);
+    else if (kp == 2) helper_passes_regs<R, 2, TS>(o, q.N, a, lane, passes);
+    else if constexpr (sizeof(R) == 4) {
+      if (kp == 3) helper_passes_regs<R, 3, TS>(o, q.N, a, lane, passes);
+      else helper_passes_regs<R, 4, TS>(o, q.N, a, lane, passes);
+    }
   }
   __syncthreads();
   R total = pcost[0 * kWave + lane] + pcost[1 * kWave + lane] + pcost[2 * kWave + lane];
   R pen = (R)0, pen0 = (R)0;
 #pragma unroll
-  for (int w = 0; w < W; ++w) { pen += ppen[w * kWave + lane]; pen0 += ppen[(W + w) * kWave + lane]; }
+  for (int w = 0; w < W; ++w) {
+#pragma unroll
+    for (int h = 0; h < SUBS; ++h) { pen += ppen[w * kWave + h * TS + tl]; pen0 += ppen[(W + w) * kWave + h * TS + tl]; }
+  }
   total += pen;
   if (a == 0 && live) {
     if (cost_first != nullptr) cost_first[b] = pcost[3 * kWave + lane] + pcost[4 * kWave + lane] + pcost[5 * kWave + lane] + pen0;
     if (penalty != nullptr) penalty[b] = pen;
   }
-  rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
+  if constexpr (SUBS == 1) {
+    rollout_epilogue<R>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk : nullptr, index_base);
+  } else {
+    rollout_epilogue<R, true>(live && a == 0, b, total, cost, (a == 0 && key != nullptr) ? key + blk / SUBS : nullptr, index_base);
+  }
 }
 
 // One projected gradient step as its own launch: T_out = clip(T - step * g, thrust box).  The host-chained counterpart of one
@@ -1963,20 +2122,27 @@ int rollout_iterate_obstacles_impl(const se3mpc_params* p, int B, int ld, int nb
   hipStream_t s = (hipStream_t)stream;
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
   const bool has_bucket = sizeof(R) == 4 && N > 16 && N <= 32;
-  // eight wavefronts per workgroup while that still leaves SIMDs idle (1024 single-wave slots on the chip), three beyond
-  const int forced_w = (g_rollout_variant >> 7) & 3;        // se3mpc_set_rollout_variant(+128 / +256): 3 / 8 wavefronts (as se3mpc_rollout_obstacles_*)
-  const bool wide = forced_w == 2 || (forced_w == 0 && (long)nblk * nbatch * 8 <= 1024);
+  // the wide shape (7 wavefronts on 32 trajectories) while it leaves no workgroup waiting for a CU, the narrow one (3 on 64) beyond;
+  // se3mpc_set_rollout_variant(+128 / +256) forces narrow / wide
+  const int forced_w = (g_rollout_variant >> 7) & 3;
+  const bool wide = forced_w == 2 || (forced_w == 0 && (long)grid_for(B, kObsWideTS) * nbatch <= 256);
   const int Kpad = (K + 7) / 8 * 8;
-#define SE3MPC_ITER_OBS(NN, REG, FL, WW)                                                                                            \
-  if (((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R) > 64 * 1024)                            \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_iterate_obstacles_kernel<R, NN, REG, FL, WW>),                  \
-                              hipFuncAttributeMaxDynamicSharedMemorySize,                                                            \
-                              (int)(((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R)));        \
-  hipLaunchKernelGGL((rollout_iterate_obstacles_kernel<R, NN, REG, FL, WW>), dim3(nblk, nbatch), dim3(64 * WW),                      \
-                     ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R), s, q, B, ld, iters, (R)step, \
-                     p0, v0, goal, Tin, Tout, cost_first, cost, gradT, spheres, K, (R)obstacle_weight, penalty, key, index_base)
+  if (wide && key != nullptr && kObsWideTS < kWave) {
+    // two workgroups fold into each key slot with atomicMin: start from the dead-lane sentinel
+    if (hipMemsetAsync(key, 0xFF, (size_t)nbatch * nblk * sizeof(unsigned long long), s) != hipSuccess) return SE3MPC_ERR_LAUNCH;
+  }
+#define SE3MPC_ITER_OBS(NN, REG, FL, WW, TT)                                                                                        \
+  {                                                                                                                                 \
+    const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(6 + 2 * WW) * kWave) * sizeof(R);                          \
+    if (lds > 64 * 1024)                                                                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_iterate_obstacles_kernel<R, NN, REG, FL, WW, TT>),            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                              \
+    hipLaunchKernelGGL((rollout_iterate_obstacles_kernel<R, NN, REG, FL, WW, TT>), dim3(grid_for(B, TT), nbatch), dim3(64 * WW),     \
+                       lds, s, q, B, ld, iters, (R)step, p0, v0, goal, Tin, Tout, cost_first, cost, gradT, spheres, K,              \
+                       (R)obstacle_weight, penalty, key, index_base);                                                               \
+  }
 #define SE3MPC_ITER_OBS_W(NN, REG, FL) \
-  if (wide) { SE3MPC_ITER_OBS(NN, REG, FL, 8); } else { SE3MPC_ITER_OBS(NN, REG, FL, 3); }
+  if (wide) SE3MPC_ITER_OBS(NN, REG, FL, kObsWideW, kObsWideTS) else SE3MPC_ITER_OBS(NN, REG, FL, 3, kWave)
   if (has_reg) {
     switch (N) {
       case 6: SE3MPC_ITER_OBS_W(6, true, 7); break;

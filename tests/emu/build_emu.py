@@ -12,7 +12,7 @@ OUT = os.path.join(HERE, "libse3mpc_emu.so")
 
 def build(force: bool = False) -> str:
     srcs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
-    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".inc"))]
     deps += [os.path.join(ROOT, "include", "se3mpc.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
              os.path.join(HERE, "wave_ops.hpp")]
     deps = [d for d in deps if os.path.exists(d)]

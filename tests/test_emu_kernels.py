@@ -49,6 +49,13 @@ def test_rollout_iterate_obstacles(emu_ops, dt, N, B):
     pc.check_rollout_iterate_obstacles(harness(emu_ops, dt), N, B, seed=N, iters=3)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("K", [17, 28, 40])
+def test_rollout_iterate_obstacles_table_sizes(emu_ops, dt, K):
+    # the helpers' register-resident sphere table holds 8 / 16 / 24 / 32 spheres (f64: 8 / 16); longer tables are swept from LDS by everyone
+    pc.check_rollout_iterate_obstacles(harness(emu_ops, dt), 6, 20, seed=K, iters=2, K=K)
+
+
 def test_keys_with_nonfinite_costs(emu_ops):
     pc.check_key_nonfinite(harness(emu_ops, np.float32))
 

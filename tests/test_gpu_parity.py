@@ -458,6 +458,14 @@ def test_rollout_iterate_obstacles(gpu_ops, dt, N, B):
     print(f"N={N} {np.dtype(dt).name}: largest penalty in the batch {worst_pen:.3g}")
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("K", [17, 28, 40])
+def test_rollout_iterate_obstacles_table_sizes(gpu_ops, dt, K):
+    """Sphere tables past the named 16: the helper wavefronts keep 8 / 16 / 24 / 32 spheres in registers (f64: 8 / 16), longer tables are
+    swept from LDS by every wavefront; same checks, among them 3 == 8 wavefronts bit for bit."""
+    pc.check_rollout_iterate_obstacles(harness(gpu_ops, dt), 20, 150, seed=K, iters=4, K=K)
+
+
 def test_rollout_iterate_obstacles_full_size(gpu_ops):
     """BASELINE config 3 inside the loop: horizon 50, 8192 trajectories, 16 spheres, 16 iterations in ONE launch == 16 one-iteration
     launches bit for bit; a 128-trajectory sample against the host-chained oracle; the penalty never grows along the descent of a

@@ -24,3 +24,24 @@ for _ in range(20): ops.rollout_iterate(prm, q0, w0, gl, T, K, 1e-3, out=(Tout, 
 for _ in range(20): ops.rollout_obstacles(prm, q0, w0, gl, T, sph)
 torch.cuda.synchronize()
 print("done", B, K)
+
+
+def timed(fn, reps=30):
+    for _ in range(5): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+# HIP-event timings (meaningful without the tracer): microseconds per launch at K = 0 and K, per pass in between
+for name, wsel in (("3 wavefronts", 128), ("8 wavefronts", 256), ("auto", 0)):
+    ops.lib.set_rollout_variant(wsel)
+    t0 = timed(lambda: ops.rollout_iterate(prm, q0, w0, gl, T, 0, 1e-3, out=(Tout, cost, grad), spheres=sph, obstacle_weight=1000.0, want_penalty=False))
+    tk = timed(lambda: ops.rollout_iterate(prm, q0, w0, gl, T, K, 1e-3, out=(Tout, cost, grad), spheres=sph, obstacle_weight=1000.0, want_penalty=False))
+    print(f"obstacle-aware loop, {name}: K=0 {t0:.1f} us, K={K} {tk:.1f} us, {(tk - t0) / max(K, 1):.2f} us per pass")
+ops.lib.set_rollout_variant(0)
+tk = timed(lambda: ops.rollout_iterate(prm, q0, w0, gl, T, K, 1e-3, out=(Tout, cost, grad)))
+print(f"plain loop K={K}: {tk:.1f} us")
