@@ -814,15 +814,17 @@ def closed_loop_leg(torch, ops, dev):
             torch.cuda.synchronize()
             t1.append(time.perf_counter() - t0)
         e1 = float(np.median(t1))
-        res[name] = {"one_launch_wall_ms_per_monte_carlo": e1 * 1e3, "one_launch_runs_per_s": S / e1, "one_launch_plans_per_s": S * cycles / e1,
-                     "one_launch_control_steps_per_s": S * cycles * substeps / e1, "one_launch_equals_two_launch_form": bool(torch.equal(pos1, pos)),
-                     "wall_ms_per_monte_carlo": el * 1e3, "runs_per_s": S / el, "plans_per_s": S * cycles / el,
-                     "control_steps_per_s": S * cycles * substeps / el, "finite": bool(torch.isfinite(pos).all()),
-                     "hipgraph_wall_ms_per_monte_carlo": eg * 1e3, "hipgraph_runs_per_s": S / eg,
-                     "hipgraph_equals_eager": bool(torch.equal(outg["pos"], pos))}
+        # the headline keys are the product's own path for this workload (the whole run in ONE launch); the two-launch-per-cycle forms it is
+        # bit-identical to stay beside it
+        res[name] = {"wall_ms_per_monte_carlo": e1 * 1e3, "runs_per_s": S / e1, "plans_per_s": S * cycles / e1,
+                     "control_steps_per_s": S * cycles * substeps / e1, "form": "one launch (se3mpc_monte_carlo_*)",
+                     "finite": bool(torch.isfinite(pos1).all()), "equals_two_launch_form": bool(torch.equal(pos1, pos)),
+                     "two_launch_wall_ms_per_monte_carlo": el * 1e3, "two_launch_runs_per_s": S / el,
+                     "two_launch_hipgraph_wall_ms_per_monte_carlo": eg * 1e3, "two_launch_hipgraph_runs_per_s": S / eg,
+                     "two_launch_hipgraph_equals_eager": bool(torch.equal(outg["pos"], pos))}
         del replay
     return {"what": f"{S} closed-loop runs x {cycles} planning cycles x {substeps} control+simulator steps (horizon-6 plans, DI defaults), "
-                    "2 launches per cycle (wall_ms_per_monte_carlo, hipgraph_*) or the whole run in ONE launch (one_launch_*), no host arithmetic", **res}
+                    "the whole run in ONE launch (wall_ms_per_monte_carlo) beside 2 launches per cycle, eager and as one hipGraph (two_launch_*); no host arithmetic", **res}
 
 
 def sweep(torch, ops, prm, dev, N):

@@ -1333,8 +1333,8 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
 #pragma unroll
         for (int jj = 0; jj < kSphereChunk / 2; ++jj) {
           const f2 dx = px2 - cx[jj], dy = py2 - cy[jj], dz = pz2 - cz[jj];
-          const f2 cj = (dx * dx + dy * dy + dz * dz) - r2[jj];
-          mn = fminf(mn, fminf(cj[0], cj[1]));
+          const f2 cj = dz * dz + (dy * dy + (dx * dx - r2[jj]));          // three fused multiply-adds (padding rows: r2 = -inf, residual +inf)
+          mn = __builtin_fminf(__builtin_fminf(mn, cj[0]), cj[1]);          // one v_min3_f32
           vs2 += f2{fmaxf(0.0f, -cj[0]), fmaxf(0.0f, -cj[1])};
         }
       }
@@ -1355,7 +1355,7 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
 #pragma unroll
         for (int jj = 0; jj < kSphereChunk; ++jj) {
           const R dx = px - cx[jj], dy = py - cy[jj], dz = pz - cz[jj];
-          const R cj = (dx * dx + dy * dy + dz * dz) - r2[jj];
+          const R cj = dz * dz + (dy * dy + (dx * dx - r2[jj]));
           mn = fmin(mn, cj);
           vs += fmax((R)0, -cj);
         }
@@ -2122,10 +2122,10 @@ int rollout_iterate_obstacles_impl(const se3mpc_params* p, int B, int ld, int nb
   hipStream_t s = (hipStream_t)stream;
   const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
   const bool has_bucket = sizeof(R) == 4 && N > 16 && N <= 32;
-  // the wide shape (7 wavefronts on 32 trajectories) while it leaves no workgroup waiting for a CU, the narrow one (3 on 64) beyond;
-  // se3mpc_set_rollout_variant(+128 / +256) forces narrow / wide
+  // the wide shape (7 wavefronts on 32 trajectories) at every size: measured 2.2x the narrow one (3 wavefronts on 64, LDS-resident sphere
+  // table) from 8192 to 262144 trajectories (profiles/r03_cfg3_loop_shapes.txt); se3mpc_set_rollout_variant(+128) forces the narrow one
   const int forced_w = (g_rollout_variant >> 7) & 3;
-  const bool wide = forced_w == 2 || (forced_w == 0 && (long)grid_for(B, kObsWideTS) * nbatch <= 256);
+  const bool wide = forced_w != 1;
   const int Kpad = (K + 7) / 8 * 8;
   if (wide && key != nullptr && kObsWideTS < kWave) {
     // two workgroups fold into each key slot with atomicMin: start from the dead-lane sentinel

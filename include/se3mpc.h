@@ -235,7 +235,9 @@ int se3mpc_rollout_iterate_f64(const se3mpc_params* p, int B, int ld, int nbatch
  * obstacle_weight, :63 = 1000, is never read).  The exact gradient of the penalty reaches the thrust sequence through the same
  * adjoint sweep.  spheres: [K][4] rows (cx, cy, cz, r) as se3mpc_rollout_obstacles_* (0 <= K <= SE3MPC_MAX_SPHERES; K = 0 is the
  * plain loop's numbers at the obstacle form's speed).  cost / cost_first include the penalty; penalty: NULL or [B] = the penalty
- * alone at T_out (0: the plan keeps the margin of every sphere at every step).  Everything else as se3mpc_rollout_iterate_*. */
+ * alone at T_out (0: the plan keeps the margin of every sphere at every step).  Everything else as se3mpc_rollout_iterate_*.
+ * wave_keys: written inside the launch (the library presets the [nbatch][ceil(B/64)] slots itself: workgroups of 32 trajectories fold
+ * pairwise into a slot). */
 int se3mpc_rollout_iterate_obstacles_f32(const se3mpc_params* p, int B, int ld, int nbatch, int iters, double step, const float* p0,
                                          const float* v0, const float* goal, const float* T_in, float* T_out, float* cost_first,
                                          float* cost, float* gradT, const float* spheres, int K, double obstacle_weight,
@@ -259,7 +261,9 @@ int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uin
  * else 3).  variant + 8 * (flags + 1) forces the memory-policy
  * flags of the benchmarked instantiation (horizon 30, f32, gradient): bit 0 nt loads, bit 1 nt stores,
  * bit 2 XCD-contiguous block order; the default is all three (7).  + 128 / + 256 forces the workgroup of
- * se3mpc_rollout_obstacles_* to 3 / 8 wavefronts (default: 8 while 8 x workgroups <= 1024, else 3).  + 512 / + 1024: the
+ * se3mpc_rollout_obstacles_* to 3 / 8 wavefronts (default: 8 while 8 x workgroups <= 1024, else 3); + 128 also forces
+ * se3mpc_rollout_iterate_obstacles_* to its narrow shape (3 wavefronts on 64 trajectories, sphere table in LDS; default: 7 wavefronts on
+ * 32 trajectories, four of them helpers with the table in registers).  + 512 / + 1024: the
  * write-heavy float32 lane kernels never / always take their 16-byte-per-lane form (four trajectories per lane; needs B and ld
  * multiples of 4 and 16-byte aligned operands; default: from 262144 trajectories up).
  * All compute the same quantities. */

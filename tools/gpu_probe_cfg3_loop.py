@@ -1,6 +1,7 @@
 """Developer probe (GPU box, under rocprofv3): BASELINE config 3 INSIDE the iteration loop -- 8192 trajectories x horizon 50 x 16 spheres,
 K = 16 obstacle-aware iterations per launch (se3mpc_rollout_iterate_obstacles_*), both workgroup shapes, beside the plain K = 16 loop at
-the same horizon and the one-shot fused rollout + obstacle kernel.  `python3 tools/gpu_probe_cfg3_loop.py [B] [K]`."""
+the same horizon and the one-shot fused rollout + obstacle kernel.  `python3 tools/gpu_probe_cfg3_loop.py [B] [K] [time]`; with `time` (not
+under the profiler) it prints HIP-event timings of both shapes instead."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import torch
@@ -24,6 +25,8 @@ for _ in range(20): ops.rollout_iterate(prm, q0, w0, gl, T, K, 1e-3, out=(Tout, 
 for _ in range(20): ops.rollout_obstacles(prm, q0, w0, gl, T, sph)
 torch.cuda.synchronize()
 print("done", B, K)
+if "time" not in sys.argv[3:]:
+    sys.exit(0)
 
 
 def timed(fn, reps=30):
@@ -37,11 +40,11 @@ def timed(fn, reps=30):
 
 
 # HIP-event timings (meaningful without the tracer): microseconds per launch at K = 0 and K, per pass in between
-for name, wsel in (("3 wavefronts", 128), ("8 wavefronts", 256), ("auto", 0)):
+for name, wsel in (("narrow (3 wavefronts x 64 trajectories, table in LDS)", 128), ("wide (7 wavefronts x 32 trajectories, table in registers; default)", 0)):
     ops.lib.set_rollout_variant(wsel)
     t0 = timed(lambda: ops.rollout_iterate(prm, q0, w0, gl, T, 0, 1e-3, out=(Tout, cost, grad), spheres=sph, obstacle_weight=1000.0, want_penalty=False))
     tk = timed(lambda: ops.rollout_iterate(prm, q0, w0, gl, T, K, 1e-3, out=(Tout, cost, grad), spheres=sph, obstacle_weight=1000.0, want_penalty=False))
-    print(f"obstacle-aware loop, {name}: K=0 {t0:.1f} us, K={K} {tk:.1f} us, {(tk - t0) / max(K, 1):.2f} us per pass")
+    print(f"B={B} obstacle-aware loop, {name}: K=0 {t0:.1f} us, K={K} {tk:.1f} us, {(tk - t0) / max(K, 1):.2f} us per pass")
 ops.lib.set_rollout_variant(0)
 tk = timed(lambda: ops.rollout_iterate(prm, q0, w0, gl, T, K, 1e-3, out=(Tout, cost, grad)))
 print(f"plain loop K={K}: {tk:.1f} us")
