@@ -546,6 +546,21 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
                 ts.append((time.perf_counter() - t0) * 1e3)
         out["shooting_plan_f32"] = {"horizon": N, "samples": B, "iterations": 16, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
                                     "p95_ms": float(np.percentile(ts, 95)), "rollouts_per_plan": B * 17}
+        # the same plan around 16 spheres (the obstacle-aware loop, se3mpc_rollout_iterate_obstacles_*): dt = 0.1 s so that the horizon covers metres
+        pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N, dt=0.1), precision="f64", device=dev)
+        rng_o = np.random.default_rng(3)
+        for c in np.round(rng_o.uniform(-2.0, 12.0, (16, 3)) * 2) / 2:
+            pl.add_obstacle(c + np.array([0.0, 0.0, 3.0]), 1.0)
+        ts = []
+        for i, g in enumerate(goals[:120]):
+            t0 = time.perf_counter()
+            pl.plan_shooting(st, g, n_samples=B, iters=16, seed=0, step=2e-3)
+            torch.cuda.synchronize()
+            if i >= 20:
+                ts.append((time.perf_counter() - t0) * 1e3)
+        out["shooting_plan_obstacles_f32"] = {"horizon": N, "samples": B, "iterations": 16, "spheres": 16, "dt": 0.1, "calls": len(ts),
+                                              "p50_ms": float(np.percentile(ts, 50)), "p95_ms": float(np.percentile(ts, 95)),
+                                              "penalty_left": float(pl.last_result.get("penalty", float("nan")))}
     prm = Params.reference_defaults(horizon=N)
     g = torch.Generator(device=dev); g.manual_seed(100 + rank)
     p0 = torch.rand(B, 3, device=dev, generator=g) * 40 - 20

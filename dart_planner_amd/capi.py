@@ -162,6 +162,7 @@ _TYPED_API = {
     "rollout_obstacles_batched": (True, [_I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, C.c_uint32, _P]),
     "rollout_iterate": (True, [_I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_uint32, _P]),
     "rollout_iterate_obstacles": (True, [_I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _D, _P, _P, C.c_uint32, _P]),
+    "shooting_finish": (True, [_I, _I, _P, _P, _I, C.c_uint32, _P, _P, _I, _D, _P, _P, _P]),
     "projected_step": (True, [_I, _I, _D, _P, _P, _P, _P]),
     "is_plan_valid": (True, [_I, _I, _P, _P, _P, _P]),
     "argmin": (False, [_I, _P, C.c_uint32, _P, _P]),

@@ -1633,6 +1633,123 @@ reduce_keys_kernel(const unsigned long long* __restrict__ wave_keys, int per_bat
 }
 
 // ------------------------------------------------------------------------------------------
+// The tail of a shooting-form plan in ONE wavefront (what SE3MPCPlanner.plan_shooting did with reduce_keys -> index_select -> cast ->
+// rollout with states -> extract -> pack -> two copies, a dozen graph nodes for ~10 us of work): fold the wave keys of the descent launch,
+// take the winner's thrust column (IO type -> double), roll it out with states and cost (the recurrence of planner.py:449-460, the
+// objective of :516-550), extract accelerations / attitudes / body rates / thrust magnitudes (:582-654, lane = step, the previous valid
+// frame fetched from its lane as in the solver's epilogue), optionally the sphere penalty left at the winner, and write the packed
+// result -- `out` may be host-mapped pinned memory, the stores then ARE the copy back.
+// out: [P (N x 3) | V (N x 3) | T (N x 3) | acc (N x 3) | att (N x 3) | rates (N x 3) | thrust (N) | cost | penalty | cost + penalty].
+// ------------------------------------------------------------------------------------------
+template <typename IO>
+__global__ void __launch_bounds__(64)
+shooting_finish_kernel(DevParams<double> q, int B, int ld, const IO* __restrict__ T, const unsigned long long* __restrict__ wave_keys,
+                       int n_slots, uint32_t index_base, const double* __restrict__ state, const double* __restrict__ spheres, int K,
+                       double w_obs, double* __restrict__ out, unsigned long long* __restrict__ key_out) {
+  __shared__ double sT[3][kWave], sP[3][kWave], sV[3][kWave], sC[3];
+  const int lane = threadIdx.x, N = q.N;
+  unsigned long long best = ~0ull;
+  for (int i = lane; i < n_slots; i += kWave) best = wave_keys[i] < best ? wave_keys[i] : best;
+  for (int off = 32; off > 0; off >>= 1) {
+    const unsigned long long o = __shfl_down(best, off, kWave);
+    best = o < best ? o : best;
+  }
+  best = __shfl(best, 0, kWave);
+  if (lane == 0 && key_out != nullptr) *key_out = best;
+  uint32_t idx = (uint32_t)(best & 0xFFFFFFFFull) - index_base;
+  if (idx >= (uint32_t)B) idx = 0;                            // (every sample's cost was NaN / the slots were never written: still a defined read)
+  const bool live = lane < N;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+  if (live) {
+    t0 = (double)T[(size_t)(3 * lane + 0) * ld + idx]; t1 = (double)T[(size_t)(3 * lane + 1) * ld + idx]; t2 = (double)T[(size_t)(3 * lane + 2) * ld + idx];
+  }
+  sT[0][lane] = t0; sT[1][lane] = t1; sT[2][lane] = t2;
+  __syncthreads();
+  if (lane < 3) {                                             // one axis per lane: the double integrator of planner.py:449-460, states and sums
+    const int a = lane;
+    const AxisConsts<double> c = axis_consts<double>(q, a, q.has_goal ? state[6 + a] : 0.0);
+    double p = state[a], v = state[3 + a];
+    RolloutSums<double> s = {0, 0, 0, 0, 0};
+    for (int k = 0; k < N; ++k) {
+      const double tk = sT[a][k];
+      const double acc = tk * q.inv_mass - c.grav, dev = tk - c.hov, e = p - c.gl;
+      sP[a][k] = p; sV[a][k] = v;
+      if (k == N - 1) s.sterm = e * e; else s.sp += e * e;
+      s.sv += v * v; s.sa += acc * acc; s.st += dev * dev;
+      p = p + v * q.dt + q.half_dt2 * acc;
+      v = v + acc * q.dt;
+    }
+    s.sp += s.sterm;
+    sC[a] = axis_cost(q, s);
+  }
+  __syncthreads();
+  const double cost = sC[0] + sC[1] + sC[2];
+  // ---- extraction (planner.py:582-654), lane k = step k
+  const double mag = sqrt(t0 * t0 + t1 * t1 + t2 * t2);
+  const bool valid = live && mag > 1e-6;
+  double b1[3] = {0, 0, 0}, b2[3] = {0, 0, 0}, b3[3] = {0, 0, 0};
+  double roll = 0.0, pitch = 0.0, yaw = 0.0;
+  double n1 = 0.0;
+  if (valid) {
+    b3[0] = t0 / mag; b3[1] = t1 / mag; b3[2] = t2 / mag;
+    b1[0] = 0.0; b1[1] = -b3[2]; b1[2] = b3[1];
+    n1 = sqrt(b1[1] * b1[1] + b1[2] * b1[2]);
+    if (n1 > 1e-6) { b1[1] /= n1; b1[2] /= n1; } else { b1[0] = 1.0; b1[1] = 0.0; b1[2] = 0.0; }
+    b2[0] = b3[1] * b1[2] - b3[2] * b1[1];
+    b2[1] = b3[2] * b1[0] - b3[0] * b1[2];
+    b2[2] = b3[0] * b1[1] - b3[1] * b1[0];
+    roll = atan2(b2[2], b3[2]);
+    pitch = asin(fmin(fmax(-b1[2], -1.0), 1.0));
+    yaw = n1 > 1e-6 ? (b1[1] == 0.0 ? b1[1] : copysign(1.5707963267948966, b1[1])) : 0.0;   // atan2(b1y, b1x) with b1x exactly 0, or b1 = (1,0,0)
+  }
+  const uint64_t vmask = wave_ballot(valid);
+  const uint64_t below = vmask & ((lane == 0) ? 0ull : (~0ull >> (64 - lane)));
+  const bool has_prev = valid && below != 0ull;
+  const int pk = has_prev ? 63 - __builtin_clzll(below) : lane;
+  double q1[3], q2[3], q3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { q1[c] = group_gather<kWave>(b1[c], pk); q2[c] = group_gather<kWave>(b2[c], pk); q3[c] = group_gather<kWave>(b3[c], pk); }
+  double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+  if (has_prev) {
+    double d1[3], d2[3], d3[3];
+    for (int c = 0; c < 3; ++c) {
+      d1[c] = (b1[c] - q1[c]) / q.dt;
+      d2[c] = (b2[c] - q2[c]) / q.dt;
+      d3[c] = (b3[c] - q3[c]) / q.dt;
+    }
+    w0 = b3[0] * d2[0] + b3[1] * d2[1] + b3[2] * d2[2];
+    w1 = b1[0] * d3[0] + b1[1] * d3[1] + b1[2] * d3[2];
+    w2 = b2[0] * d1[0] + b2[1] * d1[1] + b2[2] * d1[2];
+  }
+  // ---- what is left of the sphere penalty at the winner (the objective of se3mpc_rollout_iterate_obstacles_*)
+  double pen = 0.0;
+  if (spheres != nullptr && K > 0) {
+    double pl = 0.0;
+    if (live) {
+      const double px = sP[0][lane], py = sP[1][lane], pz = sP[2][lane];
+      for (int j = 0; j < K; ++j) {
+        const double dx = px - spheres[4 * j], dy = py - spheres[4 * j + 1], dz = pz - spheres[4 * j + 2], sm = spheres[4 * j + 3] + q.margin;
+        const double h = fmax(0.0, -((dx * dx + dy * dy + dz * dz) - sm * sm));
+        pl += h * h;
+      }
+    }
+    pen = w_obs * wave_sum(pl);
+  }
+  if (live) {
+    const int k = lane;
+    double* o = out;
+    o[3 * k] = sP[0][k]; o[3 * k + 1] = sP[1][k]; o[3 * k + 2] = sP[2][k]; o += 3 * N;
+    o[3 * k] = sV[0][k]; o[3 * k + 1] = sV[1][k]; o[3 * k + 2] = sV[2][k]; o += 3 * N;
+    o[3 * k] = t0; o[3 * k + 1] = t1; o[3 * k + 2] = t2; o += 3 * N;
+    o[3 * k] = t0 / q.mass; o[3 * k + 1] = t1 / q.mass; o[3 * k + 2] = t2 / q.mass - q.grav; o += 3 * N;      // planner.py:589
+    o[3 * k] = roll; o[3 * k + 1] = pitch; o[3 * k + 2] = yaw; o += 3 * N;
+    o[3 * k] = w0; o[3 * k + 1] = w1; o[3 * k + 2] = w2; o += 3 * N;
+    o[k] = mag;                                                                                                 // planner.py:601
+  }
+  if (lane == 0) { out[19 * N] = cost; out[19 * N + 1] = pen; out[19 * N + 2] = cost + pen; }
+}
+
+// ------------------------------------------------------------------------------------------
 // Obstacle source: occupancy grid -> sphere table, on the device.
 // Replaces the selection of cloud/main_improved_threelayer.py:387-398 (and of
 // tests/test_se3_mpc_with_mapper.py:29-33): occupied = grid[occ > threshold] in grid order,
@@ -2049,7 +2166,8 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   const int W = wide ? 8 : 3;
   const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
   hipStream_t s = (hipStream_t)stream;
-  const bool has_reg = sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20);
+  const bool has_reg = (g_rollout_variant & 127) != 3 &&     // se3mpc_set_rollout_variant(3): the register-light reversible sweep, as for the plain rollout
+                       (sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20));
 #define SE3MPC_OBST_W(NN, REG, GRAD, WW)                                                                                 \
   hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW>), dim3(nblk, nbatch), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
                      goal, T, cost, gradT, spheres, K, cmin, viol, key, index_base)
@@ -2268,6 +2386,23 @@ int transpose_impl(int rows, int cols, const R* in, int ld_in, R* out, int ld_ou
   return launch_status("se3mpc_transpose");
 }
 
+template <typename IO>
+int shooting_finish_impl(const se3mpc_params* p, int B, int ld, const IO* T, const uint64_t* wave_keys, int n_slots, uint32_t index_base,
+                         const double* state, const double* spheres, int K, double obstacle_weight, double* out, uint64_t* key_out,
+                         void* stream) {
+  if (n_slots < 1 || K < 0 || K > SE3MPC_MAX_SPHERES) return SE3MPC_ERR_SHAPE;
+  int rc = check_lane_args(p, B, ld, p ? 3LL * p->horizon : 0, sizeof(IO));
+  if (rc) return rc;
+  if (B < 1) return SE3MPC_ERR_SHAPE;                          // a plan needs a sample
+  if (!std::isfinite(obstacle_weight) || obstacle_weight < 0.0) return SE3MPC_ERR_PARAM;
+  if (!T || !wave_keys || !state || !out || (K > 0 && !spheres)) return SE3MPC_ERR_NULL;
+  const DevParams<double> q = make_dev_params<double>(*p);
+  hipLaunchKernelGGL(shooting_finish_kernel<IO>, dim3(1), dim3(kWave), 0, (hipStream_t)stream, q, B, ld, T,
+                     reinterpret_cast<const unsigned long long*>(wave_keys), n_slots, index_base, state, K > 0 ? spheres : nullptr, K,
+                     obstacle_weight, out, reinterpret_cast<unsigned long long*>(key_out));
+  return launch_status("se3mpc_shooting_finish");
+}
+
 }  // namespace se3mpc
 
 // ------------------------------------------------------------------------------------------
@@ -2366,6 +2501,17 @@ extern "C" int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int 
                      reinterpret_cast<const unsigned long long*>(wave_keys), per_batch,
                      reinterpret_cast<unsigned long long*>(keys_out));
   return launch_status("se3mpc_reduce_keys");
+}
+
+extern "C" int se3mpc_shooting_finish_f32(const se3mpc_params* p, int B, int ld, const float* T, const uint64_t* wave_keys, int n_slots,
+                                          uint32_t index_base, const double* state, const double* spheres, int K, double obstacle_weight,
+                                          double* out, uint64_t* key_out, void* stream) {
+  return se3mpc::shooting_finish_impl<float>(p, B, ld, T, wave_keys, n_slots, index_base, state, spheres, K, obstacle_weight, out, key_out, stream);
+}
+extern "C" int se3mpc_shooting_finish_f64(const se3mpc_params* p, int B, int ld, const double* T, const uint64_t* wave_keys, int n_slots,
+                                          uint32_t index_base, const double* state, const double* spheres, int K, double obstacle_weight,
+                                          double* out, uint64_t* key_out, void* stream) {
+  return se3mpc::shooting_finish_impl<double>(p, B, ld, T, wave_keys, n_slots, index_base, state, spheres, K, obstacle_weight, out, key_out, stream);
 }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {

@@ -226,6 +226,35 @@ class Ops:
         self.lib.reduce_keys(self.be.ptr(wave_keys), per, nb, self.be.ptr(keys_out), self.be.stream())
         return keys_out
 
+    def shooting_finish(self, params: Params, T, wave_keys, state, out, key_out=None, spheres=None, obstacle_weight: float = 0.0, B: Optional[int] = None,
+                        index_base: int = 0):
+        """The tail of a shooting-form plan in one launch (``se3mpc_shooting_finish_*``): fold `wave_keys` (int64, flat), roll the winning column of
+        T (3N, ld) out from state = float64 (9,) [p0 | v0 | goal], extract, and write float64 out (19 N + 3,) = [P | V | T | acc | att | rates | thrust |
+        cost | penalty | cost + penalty]; key_out: int64 (1,) or None.  state, out and key_out may be pinned host tensors (read / written in place
+        over the host link); spheres: float64 (K, 4) device tensor or None."""
+        N = params.horizon
+        self._lane(T, 3 * N, "T")
+        suf = self.be.suffix(T)
+        for nm, a, n in (("state", state, 9), ("out", out, 19 * N + 3), ("key_out", key_out, 1)):
+            if a is None and nm == "key_out":
+                continue
+            if not (self.be.is_host_mapped(a) or (self.be.check(a, nm) is a)):
+                raise TypeError(f"{nm}: expected a device tensor or a pinned host tensor")
+            if int(np.prod(a.shape)) < n or str(a.dtype).rsplit(".", 1)[-1] != ("int64" if nm == "key_out" else "float64"):
+                raise ValueError(f"{nm}: expected at least {n} {'int64' if nm == 'key_out' else 'float64'} values")
+        K = 0
+        if spheres is not None:
+            self.be.check(spheres, "spheres")
+            if spheres.ndim != 2 or spheres.shape[1] != 4 or spheres.shape[0] > SE3MPC_MAX_SPHERES or str(spheres.dtype).rsplit(".", 1)[-1] != "float64":
+                raise ValueError(f"spheres: expected float64 (K<={SE3MPC_MAX_SPHERES}, 4), got {tuple(spheres.shape)} {spheres.dtype}")
+            K = spheres.shape[0]
+        self.be.check(wave_keys, "wave_keys")
+        ld = T.shape[1]
+        self.lib.call("shooting_finish", suf, self._B(ld, B), ld, self.be.ptr(T), self.be.ptr(wave_keys), int(np.prod(wave_keys.shape)), int(index_base),
+                      self.be.ptr(state), self.be.ptr(spheres if K else None), K, float(obstacle_weight), self.be.ptr(out), self.be.ptr(key_out),
+                      self.be.stream(), params=params)
+        return out
+
     def rollout_cost_grad_batched(self, params: Params, p0, v0, goal, T, cost, gradT, wave_keys=None, index_base: int = 0):
         """`nbatch` independent batches in one launch.  p0, v0, goal: (nbatch, 3, ld); T, gradT:
         (nbatch, 3N, ld); cost: (nbatch, ld); wave_keys: int64 (nbatch, ceil(ld/64)) or None (fold with

@@ -388,9 +388,9 @@ class SE3MPCPlanner(BasePlanner):
 
     def _plan_shooting_captured(self, ops, prm, p0, v0, n_samples, iters, step, sigma, seed, precision, sph=None, w_obs=1000.0) -> Trajectory:
         """plan_shooting on one rank as ONE hipGraph replay: 72 B in through a pinned buffer, the sample set (fixed by its seed) resident,
-        iterate -> fold the argmin keys -> select the winner's thrust column BY ITS DEVICE-SIDE KEY -> roll it out with states -> extract,
-        one packed result back to a pinned buffer; the host synchronises once.  Same launches, same numbers as the eager path
-        (`distributed.sharded_shooting_plan` + rollout + extract), without its ~10 host round trips."""
+        descend (``se3mpc_rollout_iterate_*`` / ``_obstacles_*``) -> ``se3mpc_shooting_finish_*`` (fold the argmin keys, roll the winner's thrust
+        column out in float64 with states, extract, one packed result stored into a pinned buffer); the host synchronises once.  Same winner and
+        thrust sequence as the eager path (`distributed.sharded_shooting_plan` + rollout + extract), without its ~10 host round trips."""
         import torch
         from ..distributed import shooting_samples
         N = prm.horizon
@@ -403,34 +403,30 @@ class SE3MPCPlanner(BasePlanner):
             dev = ops.be.device
             dt = torch.float32 if precision == "f32" else torch.float64
             io = dict(h_in=torch.zeros(9, dtype=torch.float64).pin_memory(), d_in=torch.zeros(9, dtype=torch.float64, device=dev),
-                      h_out=torch.zeros(19 * N + 1, dtype=torch.float64).pin_memory(), h_key=torch.zeros(1, dtype=torch.int64).pin_memory(),
-                      samples=shooting_samples(prm, n_samples, sigma, seed, dev, dt), wk=torch.zeros(((n_samples + 63) // 64,), dtype=torch.int64, device=dev),
-                      best=torch.zeros(1, dtype=torch.int64, device=dev))
+                      h_out=torch.zeros(19 * N + 3, dtype=torch.float64).pin_memory(), h_key=torch.zeros(1, dtype=torch.int64).pin_memory(),
+                      samples=shooting_samples(prm, n_samples, sigma, seed, dev, dt), wk=torch.zeros(((n_samples + 63) // 64,), dtype=torch.int64, device=dev))
             if K:                                                                  # the sphere table travels with every plan (the mapper refreshes it each cycle)
-                io.update(h_sph=torch.zeros((K, 4), dtype=torch.float64).pin_memory(), d_sph=torch.zeros((K, 4), dtype=torch.float64, device=dev),
-                          h_pen=torch.zeros(2, dtype=torch.float64).pin_memory())
+                io.update(h_sph=torch.zeros((K, 4), dtype=torch.float64).pin_memory(), d_sph=torch.zeros((K, 4), dtype=torch.float64, device=dev))
+
+            io["wide"] = torch.empty((3, 3, n_samples), dtype=dt, device=dev)      # (p0, v0, goal) of every sample: the lane layout of the descent
+            io["h_in_np"], io["h_out_np"], io["h_key_np"] = io["h_in"].numpy(), io["h_out"].numpy(), io["h_key"].numpy()
+            if K:
+                io["h_sph_np"] = io["h_sph"].numpy()
 
             def body():
                 io["d_in"].copy_(io["h_in"], non_blocking=True)
-                c = io["d_in"].to(dt).view(3, 3, 1)
-                wide = c.expand(3, 3, n_samples).contiguous()
+                wide = io["wide"]
+                wide.copy_(io["d_in"].view(3, 3, 1).expand(3, 3, n_samples))     # cast + broadcast in one kernel
                 sph_d = None
                 if K:
                     io["d_sph"].copy_(io["h_sph"], non_blocking=True)
                     sph_d = io["d_sph"].to(dt)
                 out = ops.rollout_iterate(prm, wide[0], wide[1], wide[2], io["samples"], iters, step, want_grad=False, wave_keys=io["wk"], index_base=0,
                                           spheres=sph_d, obstacle_weight=w_obs, want_penalty=False)
-                ops.reduce_keys(io["wk"].view(1, -1), io["best"])
-                tw = out["T"].index_select(1, io["best"] & 0xFFFFFFFF).to(torch.float64)   # the key's low word is the sample index (se3mpc_key_index)
-                one = io["d_in"].view(3, 3, 1)                                     # the winner is rolled out and extracted in f64, as the eager path does
-                cost, _, P, V = ops.rollout_cost_grad(prm, one[0], one[1], one[2], tw, want_grad=False, want_states=True)
-                acc, att, rates, thr = ops.extract(prm, tw)
-                packed = torch.cat([x.reshape(-1) for x in (P, V, tw, acc, att, rates, thr, cost)])
-                io["h_out"].copy_(packed, non_blocking=True)
-                io["h_key"].copy_(io["best"], non_blocking=True)
-                if K:                                                              # the winner's remaining penalty (f64, like its rollout)
-                    o = ops.rollout_iterate(prm, one[0], one[1], one[2], tw, 0, 0.0, want_grad=False, spheres=io["d_sph"], obstacle_weight=w_obs)
-                    io["h_pen"].copy_(torch.cat([o["penalty"].reshape(-1), o["cost"].reshape(-1)]), non_blocking=True)
+                # the tail in ONE launch (se3mpc_shooting_finish_*): fold the keys, roll the winner out in float64 with states, extract, the penalty left
+                # at it; the packed result and the key are stored straight into the pinned host buffers
+                ops.shooting_finish(prm, out["T"], io["wk"], io["d_in"], io["h_out"], key_out=io["h_key"], spheres=io["d_sph"] if K else None,
+                                    obstacle_weight=w_obs)
 
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
@@ -445,18 +441,18 @@ class SE3MPCPlanner(BasePlanner):
                 self._shooting_graphs.pop(next(iter(self._shooting_graphs)))
             g = self._shooting_graphs[key] = (graph, io)
         graph, io = g
-        io["h_in"][0:3] = torch.from_numpy(p0); io["h_in"][3:6] = torch.from_numpy(v0)
-        io["h_in"][6:9] = torch.from_numpy(np.asarray(self.goal_position, float))
+        hin = io["h_in_np"]
+        hin[0:3] = p0; hin[3:6] = v0; hin[6:9] = self.goal_position
         if K:
-            io["h_sph"].copy_(torch.from_numpy(np.ascontiguousarray(sph)))
+            io["h_sph_np"][...] = sph
         graph.replay()
         torch.cuda.current_stream(ops.be.device).synchronize()
-        r = io["h_out"].numpy()
-        kh = int(io["h_key"].numpy()[0]) & 0xFFFFFFFFFFFFFFFF
+        r = io["h_out_np"]
+        kh = int(io["h_key_np"][0]) & 0xFFFFFFFFFFFFFFFF
         blk = lambda i: r[3 * N * i:3 * N * (i + 1)].reshape(N, 3).copy()
         self.last_result = dict(cost=float(r[19 * N]), sample=int(ops.lib.key_index(kh)), owner=0, n_samples=n_samples, iters=iters, T=blk(2))
         if K:
-            self.last_result.update(penalty=float(io["h_pen"][0]), cost_with_penalty=float(io["h_pen"][1]))
+            self.last_result.update(penalty=float(r[19 * N + 1]), cost_with_penalty=float(r[19 * N + 2]))
         sol = {"positions": blk(0), "velocities": blk(1), "thrust_vectors": blk(2), "accelerations": blk(3), "attitudes": blk(4),
                "body_rates": blk(5), "thrusts": r[18 * N:19 * N].copy()}
         return self._create_trajectory_from_solution(sol, time.time())

@@ -251,6 +251,21 @@ int se3mpc_projected_step_f32(const se3mpc_params* p, int B, int ld, double step
 int se3mpc_projected_step_f64(const se3mpc_params* p, int B, int ld, double step, const double* T, const double* gradT, double* T_out,
                               void* stream);
 
+/* The tail of a shooting-form plan in ONE launch of one wavefront (the caller side of se3mpc_rollout_iterate_* / _obstacles_*, i.e. what
+ * _solve_se3_mpc does after its optimiser returns, planner.py:270-280 -> _extract_solution_from_result :582-602 -> _compute_attitudes_and_rates
+ * :604-654): fold the descent launch's wave_keys[n_slots] to the winning key (stored to key_out if not NULL), take column
+ * (key & 0xffffffff) - index_base of T ([3N][ld], the descent's T_out) as doubles, roll it out from state = (p0, v0, goal) [9 doubles; goal ignored
+ * when has_goal == 0] with the recurrence of planner.py:449-460 and the objective of :516-550, extract accelerations, attitudes, body rates and
+ * thrust magnitudes, and -- K > 0 -- the sphere penalty obstacle_weight * sum max(0, -c_kj)^2 left at that plan (spheres: [K][4] doubles, rows
+ * (cx, cy, cz, r) before the safety margin).  out: 19 N + 3 doubles = [P | V | T | acc | att | rates (N x 3 each) | thrust (N) | cost | penalty |
+ * cost + penalty]; out, key_out and state may be pinned host memory (the kernel's loads / stores then are the copies).  B >= 1. */
+int se3mpc_shooting_finish_f32(const se3mpc_params* p, int B, int ld, const float* T, const uint64_t* wave_keys, int n_slots,
+                               uint32_t index_base, const double* state, const double* spheres, int K, double obstacle_weight, double* out,
+                               uint64_t* key_out, void* stream);
+int se3mpc_shooting_finish_f64(const se3mpc_params* p, int B, int ld, const double* T, const uint64_t* wave_keys, int n_slots,
+                               uint32_t index_base, const double* state, const double* spheres, int K, double obstacle_weight, double* out,
+                               uint64_t* key_out, void* stream);
+
 /* keys_out[i] = min over wave_keys[i][0..per_batch) for i < nbatch (one small workgroup per batch). */
 int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uint64_t* keys_out, void* stream);
 

@@ -26,6 +26,9 @@ class NumpyBackend:
     def ptr(self, a):
         return 0 if a is None else a.ctypes.data
 
+    def is_host_mapped(self, a):
+        return isinstance(a, np.ndarray) and a.flags["C_CONTIGUOUS"]      # the emulated device IS host memory
+
     def stream(self):
         return 0
 

@@ -444,6 +444,61 @@ def check_rollout_iterate_obstacles(h: Harness, N: int, B: int, seed: int = 0, i
     return float(np.max(penr))
 
 
+def check_shooting_finish(h: Harness, N: int, B: int, seed: int = 0, K: int = 3, dt: float = 0.1):
+    """se3mpc_shooting_finish_* (the tail of a shooting-form plan in one launch) against the chain it replaces AND the oracle: the winner is the
+    argmin of the rollout's own keys; positions / velocities / cost = the float64 rollout of that thrust column (oracle, 1e-12 relative);
+    accelerations, attitudes, body rates, thrust magnitudes = the oracle's extraction (planner.py:582-654) of it, zero-thrust and x-axis-thrust rows
+    included; the penalty = the oracle's sphere penalty; has_goal = 0 ignores the goal."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N, dt=dt)
+    cfg = oracle_cfg(prm)
+    p0, v0, goal, T = random_batch(rng, B, N, spread=3.0)
+    p0, v0, goal = p0[0] * 0.1, v0[0], goal[0] * 0.2                  # ONE state: a plan's samples share it
+    T = T.copy()
+    if N >= 3 and B >= 2:
+        T[:, 1] = 0.0                                                 # a zero-thrust step: skipped by the frame recurrence (planner.py:618)
+        T[:, 2] = [3.0, 0.0, 0.0]                                     # thrust along x: the b1 fallback (planner.py:626-627)
+    r = lambda a: np.asarray(a).astype(h.dt).astype(float)
+    Tq = r(T)
+    sph = np.concatenate([rng.uniform(-3, 3, (K, 3)), rng.uniform(0.3, 1.0, (K, 1))], axis=1)
+    wide = lambda a: np.tile(np.asarray(a, float).reshape(1, 3), (B, 1))
+    lane = lambda a: h.lane(a, B)
+    n_slots = (B + 63) // 64
+    for has_goal in (1, 0):
+        prm_g = prm.copy(has_goal=has_goal)
+        cfg_g = oracle_cfg(prm_g)
+        keys = h.to_dev(np.zeros(n_slots, dtype=np.int64))
+        cost, *_ = h.ops.rollout_cost_grad(prm_g, lane(wide(p0)), lane(wide(v0)), lane(wide(goal)), lane(T), want_grad=False, wave_keys=keys)
+        ch = h.to_host(cost).astype(float)
+        win = int(np.argmin(ch))
+        state = h.to_dev(np.concatenate([p0, v0, goal]).astype(np.float64))
+        out = h.to_dev(np.full(19 * N + 3, np.nan))
+        key_out = h.to_dev(np.zeros(1, dtype=np.int64))
+        dsph = h.to_dev(np.ascontiguousarray(sph, dtype=np.float64))
+        h.ops.shooting_finish(prm_g, lane(T), keys, state, out, key_out=key_out, spheres=dsph, obstacle_weight=40.0)
+        o = h.to_host(out).astype(float)
+        assert int(h.ops.lib.key_index(int(h.to_host(key_out)[0]) & 0xFFFFFFFFFFFFFFFF)) == win
+        blk = lambda i: o[3 * N * i:3 * N * (i + 1)].reshape(N, 3)
+        assert np.array_equal(blk(2), Tq[win])
+        P_ref, V_ref = orc.rollout(p0[None], v0[None], Tq[win][None], cfg_g)
+        c_ref = orc.objective(orc.pack(P_ref, V_ref, Tq[win][None]), goal[None] if has_goal else None, cfg_g)
+        vec_close(blk(0), P_ref[0], 1e-12, "finish: positions")
+        vec_close(blk(1), V_ref[0], 1e-12, "finish: velocities")
+        assert abs(o[19 * N] - c_ref[0]) <= 1e-12 * abs(c_ref[0]), "finish: cost"
+        ex = orc.extract_solution(orc.pack(P_ref, V_ref, Tq[win][None])[0], cfg_g)
+        vec_close(blk(3), ex["accelerations"], 1e-12, "finish: accelerations")
+        vec_close(blk(4), ex["attitudes"], 1e-12, "finish: attitudes")
+        vec_close(blk(5), ex["body_rates"], 1e-9, "finish: body rates")
+        vec_close(o[18 * N:19 * N], ex["thrusts"], 1e-12, "finish: thrust magnitudes")
+        pen_ref, _ = orc.obstacle_penalty_grad(p0[None], v0[None], Tq[win][None], sph, cfg_g, 40.0)
+        assert abs(o[19 * N + 1] - pen_ref[0]) <= 1e-11 * max(1.0, pen_ref[0]), "finish: penalty"
+        assert o[19 * N + 2] == o[19 * N] + o[19 * N + 1]
+        # no spheres: penalty 0
+        h.ops.shooting_finish(prm_g, lane(T), keys, state, out)
+        o2 = h.to_host(out).astype(float)
+        assert o2[19 * N + 1] == 0.0 and np.array_equal(o2[:19 * N + 1], o[:19 * N + 1])
+
+
 def check_key_nonfinite(h: Harness):
     """Packed argmin keys with non-finite costs: NaN of either sign must never win (a negative NaN would sort below
     -inf in a plain sign-magnitude map) nor pass for the dead-lane sentinel; -inf wins over everything real; +inf

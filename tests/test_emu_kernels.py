@@ -56,6 +56,12 @@ def test_rollout_iterate_obstacles_table_sizes(emu_ops, dt, K):
     pc.check_rollout_iterate_obstacles(harness(emu_ops, dt), 6, 20, seed=K, iters=2, K=K)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(6, 70), (30, 200), (1, 1), (64, 65)])
+def test_shooting_finish(emu_ops, dt, N, B):
+    pc.check_shooting_finish(harness(emu_ops, dt), N, B, seed=N)
+
+
 def test_keys_with_nonfinite_costs(emu_ops):
     pc.check_key_nonfinite(harness(emu_ops, np.float32))
 

@@ -466,6 +466,13 @@ def test_rollout_iterate_obstacles_table_sizes(gpu_ops, dt, K):
     pc.check_rollout_iterate_obstacles(harness(gpu_ops, dt), 20, 150, seed=K, iters=4, K=K)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(6, 70), (30, 8192), (1, 1), (50, 1000), (64, 65)])
+def test_shooting_finish(gpu_ops, dt, N, B):
+    """The tail of a shooting-form plan in one launch (fold keys, roll the winner out, extract, penalty) against the oracle."""
+    pc.check_shooting_finish(harness(gpu_ops, dt), N, B, seed=N)
+
+
 def test_rollout_iterate_obstacles_full_size(gpu_ops):
     """BASELINE config 3 inside the loop: horizon 50, 8192 trajectories, 16 spheres, 16 iterations in ONE launch == 16 one-iteration
     launches bit for bit; a 128-trajectory sample against the host-chained oracle; the penalty never grows along the descent of a
