@@ -769,6 +769,10 @@ struct ObsCtx {
 
 // Two spheres against one position, both sweeps (table in LDS / table in registers) through this one expression so that they agree bit for bit.
 typedef float obs_f2 __attribute__((vector_size(8)));
+#ifndef SE3MPC_OBS_PACKED
+#define SE3MPC_OBS_PACKED 1
+#endif
+template <typename R> constexpr bool kObsPacked = sizeof(R) == 4 && SE3MPC_OBS_PACKED;
 // PEN = false (descent passes, whose penalty nobody reads): the gradient only.
 template <bool PEN = true>
 __device__ __forceinline__ void sphere_pair(obs_f2 px2, obs_f2 py2, obs_f2 pz2, obs_f2 cx, obs_f2 cy, obs_f2 cz, obs_f2 r2, obs_f2& pk, obs_f2& qx,
@@ -801,7 +805,7 @@ __device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const 
     R* ty = tile + ((size_t)1 * Nn + k) * kWave + lane;
     R* tz = tile + ((size_t)2 * Nn + k) * kWave + lane;
     const R px = *tx, py = *ty, pz = *tz;
-    if constexpr (sizeof(R) == 4) {
+    if constexpr (kObsPacked<R>) {
       const obs_f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz}, zero = {0.0f, 0.0f};
       obs_f2 qx = zero, qy = zero, qz = zero, pk = zero;
 #pragma unroll 4
@@ -830,11 +834,11 @@ __device__ __forceinline__ R obstacle_penalty_sweep(R* __restrict__ tile, const 
 // arithmetic.  Same expression, same order as obstacle_penalty_sweep.
 template <typename R, int KP>
 struct SphereRegs {
-  static constexpr int kPairs = sizeof(R) == 4 ? 4 * KP : 1, kOnes = sizeof(R) == 4 ? 1 : 8 * KP;
+  static constexpr int kPairs = kObsPacked<R> ? 4 * KP : 1, kOnes = kObsPacked<R> ? 1 : 8 * KP;
   obs_f2 cx2[kPairs], cy2[kPairs], cz2[kPairs], r22[kPairs];
   R cx[kOnes], cy[kOnes], cz[kOnes], r2[kOnes];
   __device__ __forceinline__ void load(const R* __restrict__ sph) {
-    if constexpr (sizeof(R) == 4) {
+    if constexpr (kObsPacked<R>) {
 #pragma unroll
       for (int i = 0; i < kPairs; ++i) {
         const R* s0 = sph + 8 * i;
@@ -865,7 +869,7 @@ __device__ __forceinline__ R obstacle_penalty_sweep_regs(R* __restrict__ tile, c
       tx[u] = tile + (size_t)(k < Nn ? k : k0) * kWave + lane;
       px[u] = tx[u][0]; py[u] = tx[u][(size_t)Nn * kWave]; pz[u] = tx[u][(size_t)2 * Nn * kWave];
     }
-    if constexpr (sizeof(R) == 4) {
+    if constexpr (kObsPacked<R>) {
       const obs_f2 zero = {0.0f, 0.0f};
       obs_f2 px2[U], py2[U], pz2[U], qx[U], qy[U], qz[U], pk[U];
 #pragma unroll
@@ -1315,7 +1319,7 @@ template <typename R>
 __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int w,
                                                int W, int lane, R& mn_out, R& vs_out) {
   R mn = INFINITY;
-  if constexpr (sizeof(R) == 4) {
+  if constexpr (kObsPacked<R>) {
     typedef float f2 __attribute__((vector_size(8)));
     f2 vs2 = {0.0f, 0.0f};
     for (int j0 = 0; j0 < Kpad; j0 += kSphereChunk) {

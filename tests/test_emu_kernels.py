@@ -308,6 +308,31 @@ def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
     assert lib._dll.se3mpc_set_solver_variant(2) == -3 and lib._dll.se3mpc_set_solver_variant(24 << 8) == -3 and lib._dll.se3mpc_set_solver_variant(0) == 0
 
 
+def test_round3_entry_points_error_codes(emu_ops):
+    """se3mpc_rollout_iterate_obstacles / shooting_finish: status codes for NULL, shape and parameter errors; keys that were never written or belong
+    to another index range still give a defined read (sample 0)."""
+    lib, be = emu_ops.lib, emu_ops.be
+    prm = capi.Params.reference_defaults(horizon=6)
+    st = lambda *args, **kw: lib.call_status(*args, **kw)
+    p = be.ptr
+    a = np.zeros((3, 4), dtype=np.float32); T = np.ones((18, 4), dtype=np.float32); f = np.zeros(4, dtype=np.float32)
+    sph = np.zeros((2, 4), dtype=np.float32)
+    ito = lambda B, K, w, sp: st("rollout_iterate_obstacles", "f32", B, 4, 1, 2, 0.5, p(a), p(a), p(a), p(T), p(T), 0, p(f), 0, sp, K, w, 0, 0, 0, 0, params=prm)
+    assert ito(0, 2, 1.0, p(sph)) == 0 and ito(4, 2, 1.0, p(sph)) == 0 and ito(4, 0, 1.0, 0) == 0
+    assert ito(4, 2, 1.0, 0) == -1 and ito(4, -1, 1.0, p(sph)) == -3 and ito(4, 257, 1.0, p(sph)) == -3
+    assert ito(4, 2, -1.0, p(sph)) == -4 and ito(4, 2, float("nan"), p(sph)) == -4
+    keys = np.full(1, -1, dtype=np.int64); state = np.zeros(9); out = np.zeros(19 * 6 + 3); sph64 = np.zeros((2, 4))
+    T = np.ones((18, 4), dtype=np.float32)                                       # (the descent above ran in place)
+    fin = lambda B, Tp, kp, ns, stp, sp, K, w, op: st("shooting_finish", "f32", B, 4, Tp, kp, ns, 0, stp, sp, K, w, op, 0, 0, params=prm)
+    assert fin(4, p(T), p(keys), 1, p(state), p(sph64), 2, 1.0, p(out)) == 0
+    assert np.array_equal(out[36:54].reshape(6, 3), np.ones((6, 3)))             # sentinel keys: sample 0's column, a defined read
+    assert fin(0, p(T), p(keys), 1, p(state), 0, 0, 0.0, p(out)) == -3           # a plan needs a sample
+    assert fin(4, 0, p(keys), 1, p(state), 0, 0, 0.0, p(out)) == -1 and fin(4, p(T), 0, 1, p(state), 0, 0, 0.0, p(out)) == -1
+    assert fin(4, p(T), p(keys), 1, 0, 0, 0, 0.0, p(out)) == -1 and fin(4, p(T), p(keys), 1, p(state), 0, 0, 0.0, 0) == -1
+    assert fin(4, p(T), p(keys), 0, p(state), 0, 0, 0.0, p(out)) == -3 and fin(4, p(T), p(keys), 1, p(state), 0, 2, 1.0, p(out)) == -1
+    assert fin(4, p(T), p(keys), 1, p(state), p(sph64), 2, float("inf"), p(out)) == -4
+
+
 def test_plan_host_entry_point(emu_ops):
     """se3mpc_plan_host_*: launch + completion ticket in one call.  Same numbers as se3mpc_solve_* on the same buffers; the ticket lands in
     the completion word; a batch that needs more than one wavefront, a NULL completion word and a stale ticket are refused."""

@@ -102,5 +102,14 @@ out["closed_loop"] = {"closed_loop_kernel_4096x15": durations(rows_of("loop", "c
                       "solve_kernel_4096_h6_tier1": durations(lsv[0::2]), "solve_kernel_4096_h6_tier2_empty": durations(lsv[1::2]),
                       "monte_carlo_kernel_4096x33x15_f32": durations([r for r in rows_of("loop", "monte_carlo_kernel") if "<float" in r["Kernel_Name"]]),
                       "monte_carlo_kernel_4096x33x15_f64": durations([r for r in rows_of("loop", "monte_carlo_kernel") if "<double" in r["Kernel_Name"]])}
-out["rollout_iterate_obstacles_cfg3"] = durations(rows_of("iter_16", "rollout_iterate_obstacles_kernel"))
+_obs = rows_of("iter_16", "rollout_iterate_obstacles_kernel")          # the leg times K = 0 / 1 / 4 / 16 in turn: keep the K = 16 launches (the longest cluster)
+if _obs:
+    _d = sorted(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in _obs)
+    _mx = _d[int(0.98 * (len(_d) - 1))]                                   # (a cold first launch is not the cluster)
+    _obs = [r for r in _obs if 0.8 * _mx < int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) < 1.25 * _mx]
+out["rollout_iterate_obstacles_cfg3_K16"] = durations(_obs)
+# the shooting-form plan's two launches (solve leg): the descent (horizon 30, 8192 samples, K = 16; plain and around 16 spheres) and the one-wavefront tail
+out["shooting_plan"] = {"rollout_iterate_kernel_K16": durations([r for r in rows_of("solve", "rollout_iterate_kernel") if int(r["Grid_Size_X"]) == 192 * (B // 64)]),
+                        "rollout_iterate_obstacles_kernel_K16": durations(rows_of("solve", "rollout_iterate_obstacles_kernel")),
+                        "shooting_finish_kernel": durations(rows_of("solve", "shooting_finish_kernel"))}
 print(json.dumps(out, indent=1))
