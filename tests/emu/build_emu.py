@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "dart_planner_amd", "csrc")
-OUT = os.path.join(HERE, "libse3mpc_emu.so")
+OUT = os.path.join(HERE, "libse3mpc_emu_san.so" if os.environ.get("SE3MPC_EMU_FLAGS") else "libse3mpc_emu.so")
 
 
 def build(force: bool = False) -> str:
@@ -16,11 +16,12 @@ def build(force: bool = False) -> str:
     deps += [os.path.join(ROOT, "include", "se3mpc.h"), os.path.join(HERE, "hip", "hip_runtime.h"),
              os.path.join(HERE, "wave_ops.hpp")]
     deps = [d for d in deps if os.path.exists(d)]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
+    if not force and not os.environ.get("SE3MPC_EMU_FLAGS") and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     cmd = ["g++", "-std=c++20", "-O1", "-g", "-fPIC", "-shared", "-ffp-contract=off",
            "-Wno-unknown-pragmas", "-Wno-attributes",
            "-I" + HERE, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+    cmd += os.environ.get("SE3MPC_EMU_FLAGS", "").split()        # e.g. -fsanitize=undefined -fno-sanitize-recover=all (a sanitizer run of the kernels on the host)
     for s in srcs:
         cmd += ["-x", "c++", s]
     cmd += ["-o", OUT]

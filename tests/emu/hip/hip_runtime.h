@@ -142,8 +142,26 @@ inline T exchange_group(T v, int src_lane_in_block, int base, int size) {
   return out;
 }
 
+// Dynamic LDS of a launch: the requested bytes are poisoned before every workgroup (a read of LDS nobody wrote shows up as garbage, as on
+// the device) and a canary page behind them must come back untouched (a store past the size the launcher asked for aborts the test run).
+constexpr size_t kLdsCanary = 4096;
+inline void lds_arm(size_t shmem) {
+  if (shmem + kLdsCanary > sizeof(g_dyn_lds)) shmem = sizeof(g_dyn_lds) - kLdsCanary;
+  std::memset(g_dyn_lds, 0x7B, shmem);
+  std::memset(g_dyn_lds + shmem, 0xA5, kLdsCanary);
+}
+inline void lds_check(size_t shmem, const char* what) {
+  if (shmem + kLdsCanary > sizeof(g_dyn_lds)) shmem = sizeof(g_dyn_lds) - kLdsCanary;
+  for (size_t i = 0; i < kLdsCanary; ++i) {
+    if (g_dyn_lds[shmem + i] != 0xA5) {
+      std::fprintf(stderr, "emu: %s stored %zu bytes past its %zu bytes of dynamic LDS\n", what, i + 1, shmem);
+      std::abort();
+    }
+  }
+}
+
 template <typename K, typename... Args>
-void launch(K kernel, dim3 grid, dim3 block, Args... args) {
+void launch(K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
   constexpr size_t kStack = 1 << 20;
   g_blockDim = block; g_gridDim = grid;
   g_body = [=]() { kernel(args...); };
@@ -164,7 +182,9 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
         makecontext(&f.ctx, (void (*)())fiber_entry, 0);
       }
       g_cur = 0;
+      lds_arm(shmem);
       swapcontext(&g_main, &g_fibers[0].ctx);
+      lds_check(shmem, __PRETTY_FUNCTION__);
     }
 }
 }  // namespace emu
@@ -174,7 +194,7 @@ void launch(K kernel, dim3 grid, dim3 block, Args... args) {
 #define blockDim (::emu::g_blockDim)
 #define gridDim (::emu::g_gridDim)
 
-#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::emu::launch(kernel, grid, block, __VA_ARGS__)
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::emu::launch(kernel, grid, block, (size_t)(shmem), __VA_ARGS__)
 
 inline void __syncthreads() { ::emu::sync(); }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }

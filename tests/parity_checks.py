@@ -375,7 +375,7 @@ def check_rollout_iterate_obstacles(h: Harness, N: int, B: int, seed: int = 0, i
     """The obstacle-aware iteration loop (the build's extension: running cost + w_obs * sum max(0, -c_kj)^2 on the rolled-out positions):
     (1) against the host-chained oracle whose penalty gradient is a closed-form chain rule, not an adjoint sweep; (2) K iterations in
     one launch == K one-iteration launches, bit for bit; (3) iters = 0: cost = rollout cost + penalty, the penalty output, cost_first;
-    (4) no spheres == the plain loop; (5) 3 and 8 wavefronts per workgroup give the same bits; (6) multi-batch == batch by batch;
+    (4) no spheres == the plain loop; (5) the narrow (3 wavefronts x 64 trajectories, table in LDS) and the wide (7 x 32, table in registers) workgroup shapes give the same bits; (6) multi-batch == batch by batch;
     (7) spheres far away: zero penalty, the plain loop's numbers.  dt = 0.1 by default so that the horizon covers metres (at the
     reference's 1/400 s a 30-step plan spans 7 cm and nothing but a sphere on top of the start would matter)."""
     rng = np.random.default_rng(seed)
@@ -423,7 +423,7 @@ def check_rollout_iterate_obstacles(h: Harness, N: int, B: int, seed: int = 0, i
         assert np.all(h.to_host(o["penalty"]) == 0)
         vec_close(h.to_host(o["T"]).astype(float), h.to_host(plain["T"]).astype(float), 2e-6 if h.dt == np.float32 else 1e-13, "no obstacle in reach vs the plain loop")
         assert np.allclose(h.to_host(o["cost"]), h.to_host(plain["cost"]), rtol=2e-6 if h.dt == np.float32 else 1e-13, atol=0)
-    # (5) 3 / 8 wavefronts per workgroup
+    # (5) narrow / wide workgroup shape
     res = {}
     for sel in (128, 256):
         h.ops.lib.set_rollout_variant(sel)
@@ -432,7 +432,7 @@ def check_rollout_iterate_obstacles(h: Harness, N: int, B: int, seed: int = 0, i
         finally:
             h.ops.lib.set_rollout_variant(0)
     for nm in ("T", "gradT"):
-        assert np.array_equal(h.to_host(res[128][nm]), h.to_host(res[256][nm])), ("3 vs 8 wavefronts", nm)
+        assert np.array_equal(h.to_host(res[128][nm]), h.to_host(res[256][nm])), ("narrow vs wide workgroup shape", nm)
     assert np.allclose(h.to_host(res[128]["cost"]), h.to_host(res[256]["cost"]), rtol=t["cost_rel"], atol=0)      # (the penalty shares are summed in another order)
     # (6) multi-batch launch, in place
     nb = 2

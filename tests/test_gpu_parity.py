@@ -452,7 +452,7 @@ def test_wave_ops_selftest(gpu_ops):
 @pytest.mark.parametrize("N,B", [(6, 300), (20, 257), (30, 1000), (50, 129), (7, 9), (24, 130), (64, 65), (1, 5)])
 def test_rollout_iterate_obstacles(gpu_ops, dt, N, B):
     """The obstacle-aware iteration loop (running cost + obstacle_weight * sum max(0, -c_kj)^2; the build's extension) at the horizons the
-    plain loop is checked at: host-chained oracle with a closed-form penalty gradient, K-in-one == K x 1 bit for bit, 3 == 8 wavefronts,
+    plain loop is checked at: host-chained oracle with a closed-form penalty gradient, K-in-one == K x 1 bit for bit, narrow == wide workgroup shape,
     no sphere in reach == the plain loop, multi-batch == batch by batch."""
     worst_pen = pc.check_rollout_iterate_obstacles(harness(gpu_ops, dt), N, B, seed=N, iters=5, K=min(5 + N // 4, 16))
     print(f"N={N} {np.dtype(dt).name}: largest penalty in the batch {worst_pen:.3g}")
@@ -462,7 +462,7 @@ def test_rollout_iterate_obstacles(gpu_ops, dt, N, B):
 @pytest.mark.parametrize("K", [17, 28, 40])
 def test_rollout_iterate_obstacles_table_sizes(gpu_ops, dt, K):
     """Sphere tables past the named 16: the helper wavefronts keep 8 / 16 / 24 / 32 spheres in registers (f64: 8 / 16), longer tables are
-    swept from LDS by every wavefront; same checks, among them 3 == 8 wavefronts bit for bit."""
+    swept from LDS by every wavefront; same checks, among them narrow == wide workgroup shape bit for bit."""
     pc.check_rollout_iterate_obstacles(harness(gpu_ops, dt), 20, 150, seed=K, iters=4, K=K)
 
 
