@@ -760,7 +760,7 @@ struct ObsCtx {
   const R* sph;       // [Kpad][4] = (cx, cy, cz, (r + margin)^2), padding rows -inf
   R* pen;             // [W][64]: each wavefront's share of the penalty, last pass
   R* pen_first;       // [W][64]: the same at the first pass (cost at T_in)
-  int Kpad, W;
+  int Kpad;
   bool axis_sweeps;   // false: the axis wavefronts only meet the barriers, the helpers (wavefronts 3 .. W-1) take every step between them
   int slot, slots;    // this lane's share of the steps: k = slot, slot + slots, ...  (TS = 32 trajectories per workgroup: a wavefront's two
                       // halves take different steps of the same 32 trajectories)
@@ -1245,7 +1245,7 @@ rollout_iterate_obstacles_kernel(DevParams<R> q, int B, int ld, int iters, R ste
   const unsigned voff = (unsigned)b * (unsigned)sizeof(R), rowb = (unsigned)ld * (unsigned)sizeof(R);
   const int a = wave_uniform((int)(threadIdx.x / kWave));
   ObsCtx<R> o;
-  o.tile = tile; o.sph = sph; o.pen = ppen; o.pen_first = ppen + W * kWave; o.Kpad = Kpad; o.W = W; o.w_obs = w_obs;
+  o.tile = tile; o.sph = sph; o.pen = ppen; o.pen_first = ppen + W * kWave; o.Kpad = Kpad; o.w_obs = w_obs;
   // (no table, or one too long for the helpers' registers: everyone sweeps from LDS)
   o.axis_sweeps = W <= 3 || Kpad == 0 || Kpad / 8 > (sizeof(R) == 4 ? 4 : 2);
   if (o.axis_sweeps) { o.slot = a * SUBS + sub; o.slots = W * SUBS; }
