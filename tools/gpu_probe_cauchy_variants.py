@@ -1,0 +1,20 @@
+import sys, torch, numpy as np
+sys.path.insert(0,'/root/repo')
+from dart_planner_amd.capi import Params
+from dart_planner_amd.ops import Ops
+ops=Ops(); dev=ops.be.device
+for N,B in ((30,8192),(6,8192),(30,65536),(50,8192)):
+    prm=Params.reference_defaults(horizon=N)
+    g=torch.Generator(device=dev); g.manual_seed(1)
+    p0=torch.rand(B,3,device=dev,generator=g)*40-20; v0=torch.rand(B,3,device=dev,generator=g)*10-5; goal=torch.rand(B,3,device=dev,generator=g)*40-20
+    for var in (0,1,0,1):
+        ops.lib.set_solver_variant(var)
+        o=None
+        for _ in range(5): o=ops.solve(prm,p0,v0,goal,out=o)
+        torch.cuda.synchronize()
+        e0,e1=torch.cuda.Event(enable_timing=True),torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): o=ops.solve(prm,p0,v0,goal,out=o)
+        e1.record(); torch.cuda.synchronize()
+        print(f"N={N} B={B} variant {var}: {e0.elapsed_time(e1)*1e3/50:.1f} us per batch solve")
+ops.lib.set_solver_variant(0)
