@@ -304,6 +304,32 @@ def main():
                              default_heading_yaw=float(conf.default_heading_yaw)))
         meta["fast_sequences"] = fast
 
+        # ------------------------------------------------------------------ F. quaternion attitudes (controller.py:770-803): a 4-vector attitude is a
+        # (w, x, y, z) quaternion, normalised before use, the identity below a norm of 1e-6.  Single calls on fresh controllers (own generator: the
+        # draws above keep their values), away from the yaw singularity (its maintain_current fallback reads att[2] of the raw 4-vector, :662).
+        rng_q = np.random.default_rng(20261005)
+        Q = 8
+        rec = {k: [] for k in ("pos", "vel", "quat", "euler", "omega", "dpos", "dvel", "dacc", "yaw", "yaw_rate", "thrust", "torque", "thrust_euler", "torque_euler")}
+        for qi in range(Q):
+            roll, pitch, yaw_c = rng_q.normal(0, 0.004, 2).tolist() + [float(rng_q.uniform(-3.0, 3.0))]       # (small errors: unsaturated torques)
+            cr, sr, cp_, sp_, cy, sy = np.cos(roll / 2), np.sin(roll / 2), np.cos(pitch / 2), np.sin(pitch / 2), np.cos(yaw_c / 2), np.sin(yaw_c / 2)
+            quat = np.array([cr * cp_ * cy + sr * sp_ * sy, sr * cp_ * cy - cr * sp_ * sy, cr * sp_ * cy + sr * cp_ * sy, cr * cp_ * sy - sr * sp_ * cy])
+            quat = quat * [1.0, 1.0, 3.0, 0.25, 1.0, 1e-3, 1e-9, 1.0][qi]                      # lengths 1, 3, 0.25, 1e-3; 1e-9: below the threshold -> identity
+            pos, vel = rng_q.normal(0, 0.5, 3), rng_q.normal(0, 0.5, 3)
+            omega = rng_q.normal(0, 0.01, 3)
+            dpos, dvel, dacc = pos + rng_q.normal(0, 0.01, 3), vel + rng_q.normal(0, 0.01, 3), rng_q.normal(0, 0.02, 3)
+            yaw, yaw_rate = (0.0 if qi == 6 else yaw_c) + float(rng_q.normal(0, 0.004)), float(rng_q.normal(0, 0.01))
+            cmd = GeometricController(tuning_profile="sitl_optimized").compute_control(mkstate(5.0, pos, vel, quat, omega), dpos.copy(), dvel.copy(), dacc.copy(), yaw, yaw_rate)
+            euler = np.zeros(3) if qi == 6 else np.array([roll, pitch, yaw_c])
+            cme = GeometricController(tuning_profile="sitl_optimized").compute_control(mkstate(5.0, pos, vel, euler, omega), dpos.copy(), dvel.copy(), dacc.copy(), yaw, yaw_rate)
+            for nm, v in (("pos", pos), ("vel", vel), ("quat", quat), ("euler", euler), ("omega", omega), ("dpos", dpos), ("dvel", dvel), ("dacc", dacc), ("yaw", yaw),
+                          ("yaw_rate", yaw_rate), ("thrust", float(cmd.thrust)), ("torque", np.array(cmd.torque, float)), ("thrust_euler", float(cme.thrust)),
+                          ("torque_euler", np.array(cme.torque, float))):
+                rec[nm].append(np.array(v, float))
+        for nm, v in rec.items():
+            out["quat_" + nm] = np.array(v)
+        meta["quaternion_calls"] = Q
+
         np.savez_compressed(os.path.join(OUT_DIR, "controller_cases.npz"), **out)
         with open(os.path.join(OUT_DIR, "controller_cases.json"), "w") as f:
             json.dump(meta, f, indent=1)

@@ -308,6 +308,26 @@ def test_round2_entry_points_error_codes_and_empty_batches(emu_ops):
     assert lib._dll.se3mpc_set_solver_variant(2) == -3 and lib._dll.se3mpc_set_solver_variant(24 << 8) == -3 and lib._dll.se3mpc_set_solver_variant(0) == 0
 
 
+def test_controller_mirror_quaternion_states_reproduce_the_reference(emu_ops, golden_controller):
+    """Quaternion attitudes through the mirror's GeometricController.compute_control (normalised, identity below 1e-6: controller.py:770-803) against
+    the commands the REFERENCE's controller returned for the same states (tests/golden/make_golden_controller.py block F: lengths 1, 3, 0.25, 1e-3
+    and 1e-9), float64 to 1e-9."""
+    from numpy_backend import TorchCpuBackend
+    from dart_planner_amd.common.types import DroneState
+    from dart_planner_amd.control.geometric_controller import GeometricController
+    g = golden_controller[0] if isinstance(golden_controller, tuple) else golden_controller
+    ops = Ops(TorchCpuBackend(), emu_ops.lib)
+    n = len(g["quat_thrust"])
+    assert n == 8
+    for i in range(n):
+        c = GeometricController(tuning_profile="sitl_optimized", precision="f64")
+        c._ops = ops; c._device = "cpu"
+        st = DroneState(timestamp=5.0, position=g["quat_pos"][i], velocity=g["quat_vel"][i], attitude=g["quat_quat"][i], angular_velocity=g["quat_omega"][i])
+        cmd = c.compute_control(st, g["quat_dpos"][i], g["quat_dvel"][i], g["quat_dacc"][i], float(g["quat_yaw"][i]), float(g["quat_yaw_rate"][i]))
+        assert abs(cmd.thrust - g["quat_thrust"][i]) <= 1e-9 * abs(g["quat_thrust"][i]), i
+        assert np.max(np.abs(np.asarray(cmd.torque) - g["quat_torque"][i])) <= 1e-9, i
+
+
 def test_round3_entry_points_error_codes(emu_ops):
     """se3mpc_rollout_iterate_obstacles / shooting_finish: status codes for NULL, shape and parameter errors; keys that were never written or belong
     to another index range still give a defined read (sample 0)."""

@@ -161,6 +161,20 @@ def test_controller_mirror_private_steps(gpu_ops):
         assert np.allclose(b3o, b3) and np.allclose(Rm.T @ Rm, np.eye(3), atol=1e-12), method
 
 
+def test_controller_mirror_quaternion_states_reproduce_the_reference(gpu_ops, golden_controller):
+    """Quaternion attitudes through the mirror against the commands the REFERENCE's controller returned for the same states
+    (make_golden_controller.py block F: lengths 1, 3, 0.25, 1e-3 and, below the 1e-6 threshold, 1e-9 -> identity), float64 to 1e-9."""
+    from dart_planner_amd.control.geometric_controller import GeometricController
+    from dart_planner_amd.common.types import DroneState
+    g, _ = golden_controller
+    for i in range(len(g["quat_thrust"])):
+        c = GeometricController(tuning_profile="sitl_optimized", precision="f64"); c._ops = gpu_ops
+        st = DroneState(timestamp=5.0, position=g["quat_pos"][i], velocity=g["quat_vel"][i], attitude=g["quat_quat"][i], angular_velocity=g["quat_omega"][i])
+        cmd = c.compute_control(st, g["quat_dpos"][i], g["quat_dvel"][i], g["quat_dacc"][i], float(g["quat_yaw"][i]), float(g["quat_yaw_rate"][i]))
+        assert abs(cmd.thrust - g["quat_thrust"][i]) <= 1e-9 * abs(g["quat_thrust"][i]), i
+        assert np.max(np.abs(np.asarray(cmd.torque) - g["quat_torque"][i])) <= 1e-9, i
+
+
 def test_controller_mirror_reset_and_quaternion_states(gpu_ops):
     """(1) reset() after a failsafe: the reference's reset (controller.py:853-869) clears the integral, the clock and the failsafe flags but
     NOT the gains its failsafe halved in place on self.config (:817-821) -- the mirror's halving count (word 10 of the device record)
