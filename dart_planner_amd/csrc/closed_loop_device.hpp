@@ -81,6 +81,9 @@ __device__ __forceinline__ void store_ctrl(double* __restrict__ s, const CtrlReg
 
 template <typename R>
 __device__ __forceinline__ R norm3(const R v[3]) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+// sin and cos of one angle with ONE argument reduction (the same two values the separate calls return)
+__device__ __forceinline__ void sin_cos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+__device__ __forceinline__ void sin_cos(double x, double& s, double& c) { sincos(x, &s, &c); }
 template <typename R>
 __device__ __forceinline__ R sign_of(R v) { return v > (R)0 ? (R)1 : (v < (R)0 ? (R)-1 : v); }   // np.sign (NaN stays NaN)
 template <typename R>
@@ -172,11 +175,14 @@ __device__ __forceinline__ void desired_frame(const CtrlDev<R>& c, int method, b
 template <typename R>
 __device__ void attitude_torque(const CtrlDev<R>& c, CtrlRegs<R>& s, R scale, const R b3[3], const R att[3], const R omega[3], R yaw_des,
                                 R yaw_rate_des, const R* Ifull, R torque_out[3], int& out_flags) {
-  const R cr = cos(att[0]), sr = sin(att[0]), cp = cos(att[1]), sp = sin(att[1]), cy = cos(att[2]), sy = sin(att[2]);
+  R cr, sr, cp, sp, cy, sy;
+  sin_cos(att[0], sr, cr); sin_cos(att[1], sp, cp); sin_cos(att[2], sy, cy);
   const R Rm[3][3] = {{cy * cp, cy * sp * sr - sy * cr, cy * sp * cr + sy * sr},   // :774-789
                       {sy * cp, sy * sp * sr + cy * cr, sy * sp * cr - cy * sr},
                       {-sp, cp * sr, cp * cr}};
-  const R yv[3] = {cos(yaw_des), sin(yaw_des), (R)0};                             // :665
+  R yc, ys;
+  sin_cos(yaw_des, ys, yc);
+  const R yv[3] = {yc, ys, (R)0};                                                 // :665
   const R n3 = norm3(b3);
   const R b3n[3] = {b3[0] / n3, b3[1] / n3, b3[2] / n3};                          // :667
   R b1[3], b2[3], cos_angle;
