@@ -219,8 +219,9 @@ __device__ void attitude_command(const CtrlDev<R>& c, CtrlRegs<R>& s, R scale, c
   R b3[3];
   if (tm > (R)1e-6) { b3[0] = tvw[0] / tm; b3[1] = tvw[1] / tm; b3[2] = tvw[2] / tm; }
   else { b3[0] = (R)0; b3[1] = (R)0; b3[2] = (R)1; }
-  const R tilt = acos(fmin(fmax(b3[2], (R)-1), (R)1));
-  if (tilt > c.max_tilt) {
+  // tilt = arccos(b3z) > max_tilt (controller.py:489-490) decided on the cosines: arccos is strictly decreasing on [-1, 1], and at the boundary the
+  // rescaling below is the identity (sf = 1), so the one rounding-width band where the two forms could disagree changes nothing continuous
+  if (fmin(fmax(b3[2], (R)-1), (R)1) < c.cos_max_tilt) {
     const R sf = c.cos_max_tilt / b3[2];
     b3[0] = b3[0] * sf; b3[1] = b3[1] * sf; b3[2] = c.cos_max_tilt;
     const R n = norm3(b3);
