@@ -576,6 +576,20 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
         torch.cuda.synchronize()
         if i >= 20:
             ts.append((time.perf_counter() - t0) * 1e3)
+    # the same call between two HIP events on its stream (both launches of the two-tier solve, without the host's share of the wall time);
+    # horizon 6 -- the reference's default -- beside the named horizon
+    def device_us(prm_, reps=100):
+        oo = None
+        for _ in range(10):
+            oo = ops.solve(prm_, p0, v0, goal, out=oo)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            oo = ops.solve(prm_, p0, v0, goal, out=oo)
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+    dev_us, dev_us_h6 = device_us(prm), device_us(Params.reference_defaults(horizon=6))
     info = ops.info_to_host(o["info"])
     mean_ms = float(np.mean(ts))
     agg = torch.tensor([B / (mean_ms * 1e-3)], dtype=torch.float64, device=dev)
@@ -584,6 +598,7 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
     out["batch_f32"] = {"horizon": N, "batch_per_gpu": B, "calls": len(ts), "p50_ms": float(np.percentile(ts, 50)),
                         "p95_ms": float(np.percentile(ts, 95)), "solves_per_s": float(agg.item()),
                         "mean_nfev": float(info["nfev"].mean()), "mean_nit": float(info["nit"].mean()),
+                        "device_us_per_batch_hip_events": dev_us, "device_us_per_batch_horizon_6": dev_us_h6,
                         "rollouts_inside_solves_per_s": float(agg.item() * info["nfev"].mean())}
     return out
 
