@@ -1,3 +1,6 @@
+"""Developer probe (GPU box): HIP-event time of the batched solve with the closed-form Cauchy point of the first iteration (default) against the
+published sequential search (se3mpc_set_solver_variant(1): SciPy's accumulation, every breakpoint of the first iteration walked one by one).
+`python tools/gpu_probe_cauchy_variants.py`."""
 import sys, torch, numpy as np
 sys.path.insert(0,'/root/repo')
 from dart_planner_amd.capi import Params

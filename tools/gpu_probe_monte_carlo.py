@@ -1,3 +1,6 @@
+"""Developer probe (GPU box): median wall time of the one-launch Monte-Carlo (se3mpc_monte_carlo_*: 4096 drones x 33 planning cycles x 15 control +
+simulator steps, bench.py's closed_loop leg), float32 and float64, with a checksum of the final positions -- for A/B runs of two builds of the
+library (SE3MPC_LIBRARY=...): same checksum = same bits.  `python tools/gpu_probe_monte_carlo.py`."""
 import sys, time, numpy as np, torch
 sys.path.insert(0,'/root/repo')
 from dart_planner_amd.capi import Params
