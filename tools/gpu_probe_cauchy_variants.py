@@ -2,7 +2,7 @@
 published sequential search (se3mpc_set_solver_variant(1): SciPy's accumulation, every breakpoint of the first iteration walked one by one).
 `python tools/gpu_probe_cauchy_variants.py`."""
 import sys, torch, numpy as np
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dart_planner_amd.capi import Params
 from dart_planner_amd.ops import Ops
 ops=Ops(); dev=ops.be.device

@@ -2,7 +2,7 @@
 simulator steps, bench.py's closed_loop leg), float32 and float64, with a checksum of the final positions -- for A/B runs of two builds of the
 library (SE3MPC_LIBRARY=...): same checksum = same bits.  `python tools/gpu_probe_monte_carlo.py`."""
 import sys, time, numpy as np, torch
-sys.path.insert(0,'/root/repo')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dart_planner_amd.capi import Params
 from dart_planner_amd.control.closed_loop import ClosedLoopMonteCarlo
 from dart_planner_amd.ops import Ops
