@@ -534,6 +534,31 @@ def solve_leg(torch, ops, dev, B, N, rank, world):
                                  "p95_ms": float(np.percentile(ts, 95)), "max_ms": float(np.max(ts)),
                                  "p50_ms_with_device_synchronize": float(np.percentile(ts_sync, 50)),
                                  "p95_ms_with_device_synchronize": float(np.percentile(ts_sync, 95))}
+    # the drop-in boundary itself: se3mpc_plan_host_* (launch on pinned buffers + completion ticket) called through ctypes with pre-computed addresses --
+    # what a C / C++ caller of the library pays per plan; the Python mirror's share is the difference to single_* above
+    import ctypes
+    for prec, tdt in (("f64", torch.float64), ("f32", torch.float32)):
+        prm1 = Params.reference_defaults(horizon=N)
+        esz = 4 if prec == "f32" else 8
+        h_in = torch.zeros((3, 1, 3), dtype=tdt, pin_memory=True); h_in[0, 0, 2] = 1.0
+        h_out = torch.empty((ops.packed_size(1, N, prec),), dtype=torch.uint8, pin_memory=True)
+        h_done = torch.zeros((8,), dtype=torch.int64, pin_memory=True)
+        o_x, o_acc, o_att, o_rates, o_thr, o_info, _ = ops._packed_offsets(1, N, esz)
+        pin, base = h_in.data_ptr(), h_out.data_ptr()
+        fn = getattr(ops.lib._dll, f"se3mpc_plan_host_{prec}")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        hin_np = h_in.numpy()
+        ts = []
+        for i, g in enumerate(goals):
+            hin_np[2, 0] = g
+            t0 = time.perf_counter()
+            rc = fn(ctypes.byref(prm1), 1, pin, pin + 3 * esz, pin + 6 * esz, 0, base + o_x, base + o_info, base + o_acc, base + o_att, base + o_rates,
+                    base + o_thr, h_done.data_ptr(), i + 1, 2000.0, stream)
+            if i >= 20:
+                ts.append((time.perf_counter() - t0) * 1e3)
+            if rc != 0:
+                raise RuntimeError(f"se3mpc_plan_host_{prec}: status {rc}")
+        out[f"single_{prec}"].update(c_abi_call_p50_ms=float(np.percentile(ts, 50)), c_abi_call_p95_ms=float(np.percentile(ts, 95)))
     # the shooting-form plan through the same mirror: 8192 thrust samples x 16 iterations in one launch, argmin, rollout + extraction of the winner
     if world == 1:
         pl = SE3MPCPlanner(SE3MPCConfig(prediction_horizon=N), precision="f64", device=dev)
