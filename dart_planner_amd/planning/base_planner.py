@@ -44,7 +44,10 @@ class BasePlanner(IPlanner):
         st["total_plans"] += 1
         st["successful_plans"] += int(bool(success))
         st["last_plan_time"] = planning_time
-        st["planning_times"] = (st["planning_times"] + [planning_time])[-_KEEP_TIMES:]
+        times = st["planning_times"]
+        times.append(planning_time)                          # reference :98-102: the last 100 are kept
+        if len(times) > _KEEP_TIMES:
+            del times[:-_KEEP_TIMES]
 
     def reset_stats(self) -> None:
         self.planning_stats = _fresh_stats()

@@ -151,7 +151,8 @@ class SE3MPCPlanner(BasePlanner):
         if self.goal_position is None:
             self.set_goal(goal_position)
         else:
-            d = np.asarray(to_float(self.goal_position), float) - goal_position
+            g = self.goal_position                            # (set_goal stores a float ndarray; an attribute written from outside may be anything)
+            d = (g if type(g) is np.ndarray and g.dtype == np.float64 else np.asarray(to_float(g), float)) - goal_position
             if float(d @ d) > 0.25:                                             # planner.py:197-201 (norm > 0.5 m)
                 self.set_goal(goal_position)
         return current_state, self.goal_position, list(self.obstacles)
@@ -175,24 +176,66 @@ class SE3MPCPlanner(BasePlanner):
 
     # ------------------------------------------------------------------ planner.py:230-280 on the GPU
     def _solve_se3_mpc(self, current_state: DroneState) -> Dict[str, np.ndarray]:
-        p0 = np.asarray(to_float(current_state.position), dtype=float).reshape(1, 3)
-        v0 = np.asarray(to_float(current_state.velocity), dtype=float).reshape(1, 3)
-        goal = None if self.goal_position is None else np.asarray(self.goal_position, float).reshape(1, 3)
         x0 = None
         if self.warm_start_enabled and self.last_solution is not None:          # planner.py:287-289
             x0 = self._create_warm_start(current_state, self.se3_config.prediction_horizon).reshape(1, -1)
-        res = self._solve_batch(p0, v0, goal, x0, self.precision)
-        info = res["info"][0]
-        converged = int(info["status"]) == 0                                     # result.success
+        io = self._io
+        N = self.se3_config.prediction_horizon
+        if io.get("one_wave") and io["key"] == (1, N, "f32" if self.precision == "f32" else "f64", True) and self.host_mapped_max_problems >= 1:
+            # steady state of the per-plan path: the three 3-vectors go straight into the pinned input rows (NumPy casts and broadcasts on assignment)
+            sol, (fun, nit, nfev, status, task) = self._solve_one(io, to_float(current_state.position), to_float(current_state.velocity),
+                                                                 None if self.goal_position is None else to_float(self.goal_position), x0, N)
+        else:
+            p0 = np.asarray(to_float(current_state.position), dtype=float).reshape(1, 3)
+            v0 = np.asarray(to_float(current_state.velocity), dtype=float).reshape(1, 3)
+            goal = None if self.goal_position is None else np.asarray(self.goal_position, float).reshape(1, 3)
+            res = self._solve_batch(p0, v0, goal, x0, self.precision)
+            fun, nit, nfev, status, task = res["info"][0].item()                 # (fun, nit, nfev, status, task): Python scalars in one call
+            sol = {k: res[k][0] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes", "body_rates", "thrusts")}
+        converged = status == 0                                                  # result.success
         self.convergence_history.append(converged)
-        self.last_result = dict(nit=int(info["nit"]), nfev=int(info["nfev"]), status=int(info["status"]),
-                                fun=float(info["fun"]), message=TASK_MESSAGES.get(int(info["task"]), ""))
+        self.last_result = dict(nit=nit, nfev=nfev, status=status, fun=fun, message=TASK_MESSAGES.get(task, ""))
         if not converged:
             self.logger.warning("SE(3) MPC optimization did not converge: %s", self.last_result["message"])
         if self.receding_horizon:
-            self.last_solution = {k: res[k][0].copy() for k in ("positions", "velocities", "thrust_vectors")}
-        return {k: res[k][0] for k in ("positions", "velocities", "thrust_vectors", "accelerations", "attitudes",
-                                       "body_rates", "thrusts")}
+            self.last_solution = {k: sol[k].copy() for k in ("positions", "velocities", "thrust_vectors")}
+        return sol
+
+    def _solve_one(self, io, p0, v0, goal, x0, N):
+        """The steady state of ONE plan (what `_solve_batch` does for B = 1 once its pinned buffers exist, without its general-case bookkeeping):
+        inputs into the pinned buffer, `se3mpc_plan_host_*` (launch + completion ticket), one copy of the packed result, views into the copy."""
+        prm = self._params(has_goal=int(goal is not None))
+        hin = io["h_in_np"]
+        hin[0] = p0; hin[1] = v0
+        if goal is not None:
+            hin[2] = goal
+        hx0 = 0
+        if x0 is not None:
+            io["h_x0_np"][...] = x0
+            hx0 = io["ptr_x0"]
+        pin = io["ptr_in"]
+        io["ticket"] = ticket = io["ticket"] + 1
+        rc = io["plan_fn"](ctypes.byref(prm), 1, pin[0], pin[1], pin[2] if prm.has_goal else 0, hx0, *io["ptr_out"], io["ptr_done"], ticket, 2000.0,
+                           io["plan_stream_handle"])
+        if rc != 0:
+            self._get_ops().lib._check("se3mpc_plan_host", rc)
+        fast = io.get("fast")
+        if fast is None:                                      # views of the pinned result, formed once per buffer set
+            suf = io["key"][2]
+            esz, dt = (4, np.float32) if suf == "f32" else (8, np.float64)
+            o_x, o_acc, o_att, o_rates, o_thr, o_info, _ = self._get_ops()._packed_offsets(1, N, esz)
+            nfl = (o_thr + N * esz) // esz
+            fl = np.frombuffer(io["h_out_np"], dtype=dt, count=nfl)
+            from ..ops import INFO_DTYPE
+            fast = io["fast"] = (fl, np.frombuffer(io["h_out_np"], dtype=INFO_DTYPE, count=1, offset=o_info), o_acc // esz, o_att // esz, o_rates // esz, o_thr // esz,
+                                 esz == 4)
+        fl, info, a_acc, a_att, a_rates, a_thr, widen = fast
+        allf = fl.astype(np.float64) if widen else fl.copy()                     # ONE copy: the arrays below do not alias the pinned buffer
+        n3 = 3 * N
+        sol = {"positions": allf[0:n3].reshape(N, 3), "velocities": allf[n3:2 * n3].reshape(N, 3), "thrust_vectors": allf[2 * n3:3 * n3].reshape(N, 3),
+               "accelerations": allf[a_acc:a_acc + n3].reshape(N, 3), "attitudes": allf[a_att:a_att + n3].reshape(N, 3),
+               "body_rates": allf[a_rates:a_rates + n3].reshape(N, 3), "thrusts": allf[a_thr:a_thr + N]}
+        return sol, info[0].item()
 
     def _solve_batch(self, p0, v0, goal, x0, precision, want_trajectory=True) -> Dict[str, np.ndarray]:
         """B problems in one launch; host float64 arrays in, host float64 arrays out.  Steady state: the
@@ -621,7 +664,10 @@ class SE3MPCPlanner(BasePlanner):
     # ------------------------------------------------------------------ planner.py:656-757
     def _create_trajectory_from_solution(self, solution: Dict[str, np.ndarray], start_time: float) -> Trajectory:
         N = len(solution["positions"])
-        timestamps = start_time + np.arange(N) * self.se3_config.dt
+        key = (N, self.se3_config.dt)
+        if getattr(self, "_stamp_key", None) != key:                            # k * dt of the horizon, formed once per (N, dt)
+            self._stamp_key, self._stamp_offsets = key, np.arange(N) * self.se3_config.dt
+        timestamps = start_time + self._stamp_offsets
         return Trajectory(timestamps=timestamps, positions=solution["positions"], velocities=solution["velocities"],
                           accelerations=solution["accelerations"], attitudes=solution["attitudes"],
                           body_rates=solution["body_rates"], thrusts=solution["thrusts"],
