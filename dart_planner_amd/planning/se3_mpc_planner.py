@@ -115,10 +115,8 @@ class SE3MPCPlanner(BasePlanner):
     def _params(self, **overrides) -> Params:
         c = self.se3_config
         has_goal = int(self.goal_position is not None)
-        # the struct is rebuilt only when a value it carries changed (the config object is mutable)
-        sig = (c.prediction_horizon, c.dt, self.mass, self.gravity, c.position_weight, c.velocity_weight,
-               c.acceleration_weight, c.thrust_weight, c.max_velocity, c.max_acceleration, c.max_thrust, c.min_thrust,
-               c.max_tilt_angle, c.safety_margin, c.max_iterations, c.convergence_tolerance, has_goal)
+        # the struct is rebuilt only when something it carries changed: the (frozen) config object itself, the vehicle constants, the goal's presence
+        sig = (c, self.mass, self.gravity, has_goal)
         if self._params_sig != sig:
             self._params_cached = Params.reference_defaults(
                 horizon=c.prediction_horizon, dt=c.dt, mass=self.mass, gravity=self.gravity,
@@ -148,13 +146,14 @@ class SE3MPCPlanner(BasePlanner):
 
     def sense(self, current_state: DroneState, goal_position):
         goal_position = ensure_units(goal_position, "m", "SE3MPCPlanner.sense goal_position")
-        if self.goal_position is None:
-            self.set_goal(goal_position)
-        else:
-            g = self.goal_position                            # (set_goal stores a float ndarray; an attribute written from outside may be anything)
+        g = self.goal_position
+        if g is not None:
+            # (set_goal stores a float ndarray; an attribute written from outside may be anything)
             d = (g if type(g) is np.ndarray and g.dtype == np.float64 else np.asarray(to_float(g), float)) - goal_position
-            if float(d @ d) > 0.25:                                             # planner.py:197-201 (norm > 0.5 m)
-                self.set_goal(goal_position)
+        if g is None or float(d @ d) > 0.25:                                    # planner.py:197-201 (norm > 0.5 m)
+            self.goal_position = np.array(goal_position, dtype=float)           # = set_goal on the magnitudes already checked above
+            if self.logger.isEnabledFor(logging.DEBUG):
+                self.logger.debug("SE(3) MPC goal set to: %s", self.goal_position)
         return current_state, self.goal_position, list(self.obstacles)
 
     def plan(self, current_state: DroneState) -> Dict[str, np.ndarray]:
@@ -231,10 +230,9 @@ class SE3MPCPlanner(BasePlanner):
                                  esz == 4)
         fl, info, a_acc, a_att, a_rates, a_thr, widen = fast
         allf = fl.astype(np.float64) if widen else fl.copy()                     # ONE copy: the arrays below do not alias the pinned buffer
-        n3 = 3 * N
-        sol = {"positions": allf[0:n3].reshape(N, 3), "velocities": allf[n3:2 * n3].reshape(N, 3), "thrust_vectors": allf[2 * n3:3 * n3].reshape(N, 3),
-               "accelerations": allf[a_acc:a_acc + n3].reshape(N, 3), "attitudes": allf[a_att:a_att + n3].reshape(N, 3),
-               "body_rates": allf[a_rates:a_rates + n3].reshape(N, 3), "thrusts": allf[a_thr:a_thr + N]}
+        rows = allf[:18 * N].reshape(6 * N, 3)                                   # [P | V | T | acc | att | rates], N rows of 3 each (B = 1: the fields are adjacent)
+        sol = {"positions": rows[0:N], "velocities": rows[N:2 * N], "thrust_vectors": rows[2 * N:3 * N], "accelerations": rows[3 * N:4 * N],
+               "attitudes": rows[4 * N:5 * N], "body_rates": rows[5 * N:6 * N], "thrusts": allf[a_thr:a_thr + N]}
         return sol, info[0].item()
 
     def _solve_batch(self, p0, v0, goal, x0, precision, want_trajectory=True) -> Dict[str, np.ndarray]:
