@@ -166,9 +166,15 @@ int solve_impl(const se3mpc_params* p, int B, const IO* p0, const IO* v0, const 
   const int waves = (int)(((long)B * G + kWave - 1) / kWave);
   if (done != nullptr && waves != 1) return SE3MPC_ERR_SHAPE;
 #define SE3MPC_SOLVE_CASE(GG)                                                                                               \
-  if (solve_lds_bytes(q.mlds, GG, sizeof(IO)) > 64 * 1024)                                                                  \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<IO, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)solve_lds_bytes(q.mlds, GG, sizeof(IO)));                                                 \
+  {                                                                                                                         \
+    /* the attribute is raised once per instantiation and size, not on every plan (it is a driver call) */                  \
+    static size_t lds_allowed = 64 * 1024;                                                                                  \
+    if (solve_lds_bytes(q.mlds, GG, sizeof(IO)) > lds_allowed) {                                                            \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&solve_kernel<IO, GG>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)solve_lds_bytes(q.mlds, GG, sizeof(IO)));                                               \
+      lds_allowed = solve_lds_bytes(q.mlds, GG, sizeof(IO));                                                                \
+    }                                                                                                                       \
+  }                                                                                                                         \
   hipLaunchKernelGGL((solve_kernel<IO, GG>), dim3(waves), dim3(kWave), solve_lds_bytes(q.mlds, GG, sizeof(IO)), s, q, B, p0, \
                      v0, goal, x0, X, info, acc, att, rates, thrust, done, ticket)
 #define SE3MPC_SOLVE_LAUNCH()               \
