@@ -444,6 +444,38 @@ def check_rollout_iterate_obstacles(h: Harness, N: int, B: int, seed: int = 0, i
     return float(np.max(penr))
 
 
+def check_iterate_keys(h: Harness, N: int, B: int, seed: int = 0, K: int = 5, iters: int = 2, index_base: int = 0):
+    """The argmin keys fused into both iteration loops: min over the [ceil(B/64)] slots == (cost, index) of np.argmin over the launch's own costs (ties
+    to the lowest index), for the plain loop, and for the obstacle-aware loop in its narrow shape (one workgroup per slot, plain stores) and its wide
+    one (two workgroups of 32 trajectories fold into a slot with atomicMin; the launcher presets the slots), with slots pre-filled with garbage."""
+    rng = np.random.default_rng(seed)
+    prm = Params.reference_defaults(horizon=N, dt=0.1)
+    p0, v0, goal, T = random_batch(rng, B, N, spread=3.0)
+    p0 = p0 * 0.1; goal = goal * 0.2
+    sph = np.concatenate([rng.uniform(-3, 3, (K, 3)), rng.uniform(0.3, 1.0, (K, 1))], axis=1)
+    lp0, lv0, lg, lT = h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B)
+    dsph = h.to_dev(np.ascontiguousarray(sph.astype(h.dt)))
+    n_slots = (B + 63) // 64
+    for name, kw, sel in (("plain", {}, 0), ("obstacles narrow", dict(spheres=dsph, obstacle_weight=40.0), 128), ("obstacles wide", dict(spheres=dsph, obstacle_weight=40.0), 0)):
+        keys = h.to_dev(np.full(n_slots, 12345, dtype=np.int64))                 # garbage: every slot must be overwritten / preset by the launch
+        h.ops.lib.set_rollout_variant(sel)
+        try:
+            out = h.ops.rollout_iterate(prm, lp0, lv0, lg, lT, iters, 2e-3, want_grad=False, wave_keys=keys, index_base=index_base, **kw)
+        finally:
+            h.ops.lib.set_rollout_variant(0)
+        cost = h.to_host(out["cost"]).astype(np.float32)
+        kh = h.to_host(keys).astype(np.int64).view(np.uint64)
+        best = int(kh.min())
+        idx, kc = h.ops.lib.key_index(best), h.ops.lib.key_cost(best)
+        win = int(np.argmin(cost))
+        assert idx - index_base == win and np.float32(kc) == cost[win], (name, idx, win, kc, cost[win])
+        # every slot holds the minimum of its own 64 trajectories
+        for sl in range(n_slots):
+            lo, hi = 64 * sl, min(64 * sl + 64, B)
+            w = lo + int(np.argmin(cost[lo:hi]))
+            assert h.ops.lib.key_index(int(kh[sl])) - index_base == w, (name, sl)
+
+
 def check_shooting_finish(h: Harness, N: int, B: int, seed: int = 0, K: int = 3, dt: float = 0.1):
     """se3mpc_shooting_finish_* (the tail of a shooting-form plan in one launch) against the chain it replaces AND the oracle: the winner is the
     argmin of the rollout's own keys; positions / velocities / cost = the float64 rollout of that thrust column (oracle, 1e-12 relative);

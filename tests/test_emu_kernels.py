@@ -62,6 +62,12 @@ def test_shooting_finish(emu_ops, dt, N, B):
     pc.check_shooting_finish(harness(emu_ops, dt), N, B, seed=N)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+def test_iteration_loop_keys(emu_ops, dt):
+    pc.check_iterate_keys(harness(emu_ops, dt), 6, 200, seed=1)
+    pc.check_iterate_keys(harness(emu_ops, dt), 6, 33, seed=2, index_base=1000)
+
+
 def test_keys_with_nonfinite_costs(emu_ops):
     pc.check_key_nonfinite(harness(emu_ops, np.float32))
 

@@ -473,6 +473,14 @@ def test_shooting_finish(gpu_ops, dt, N, B):
     pc.check_shooting_finish(harness(gpu_ops, dt), N, B, seed=N)
 
 
+@pytest.mark.parametrize("dt", [np.float64, np.float32])
+@pytest.mark.parametrize("N,B", [(6, 200), (30, 70001), (50, 8192), (20, 33)])
+def test_iteration_loop_keys(gpu_ops, dt, N, B):
+    """The argmin keys of both iteration loops against np.argmin of the launch's own costs, slot by slot: plain loop, obstacle-aware loop narrow (plain
+    stores) and wide (two workgroups per slot through atomicMin on slots the launcher presets); ragged batches, an index base."""
+    pc.check_iterate_keys(harness(gpu_ops, dt), N, B, seed=N, index_base=0 if B != 33 else 5000)
+
+
 def test_rollout_iterate_obstacles_full_size(gpu_ops):
     """BASELINE config 3 inside the loop: horizon 50, 8192 trajectories, 16 spheres, 16 iterations in ONE launch == 16 one-iteration
     launches bit for bit; a 128-trajectory sample against the host-chained oracle; the penalty never grows along the descent of a
