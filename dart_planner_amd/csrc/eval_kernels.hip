@@ -2167,16 +2167,20 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   // before any wavefront has to share a SIMD), 3 otherwise; se3mpc_set_rollout_variant(+128 / +256) forces 3 / 8
   const int wsel = (g_rollout_variant >> 7) & 3;
   const bool wide = wsel == 2 || (wsel == 0 && (long long)nblk * nbatch * 8 <= 1024);
-  const int W = wide ? 8 : 3;
-  const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
-  hipStream_t s = (hipStream_t)stream;
   const bool has_reg = (g_rollout_variant & 127) != 3 &&     // se3mpc_set_rollout_variant(3): the register-light reversible sweep, as for the plain rollout
                        (sizeof(R) == 4 ? (N == 6 || N == 20 || N == 30 || N == 50) : (N == 6 || N == 20));
+  // 3 axis wavefronts + 1 helper for the exact-N = 50 register sweep: at its 2 wavefronts per SIMD a CU has 8 slots, which two
+  // 3-wavefront workgroups leave a quarter empty (64 x 8192, warm: 166 -> 161 us; shorter horizons hold 3 per SIMD and lose 3 % with
+  // a helper: profiles/r03f_cfg3_workgroup_shapes.txt); se3mpc_set_rollout_variant(+384) forces it
+  const bool four = wsel == 3 || (wsel == 0 && !wide && has_reg && N == 50);
+  const int W = wide ? 8 : (four ? 4 : 3);
+  const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
+  hipStream_t s = (hipStream_t)stream;
 #define SE3MPC_OBST_W(NN, REG, GRAD, WW)                                                                                 \
   hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW>), dim3(nblk, nbatch), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
                      goal, T, cost, gradT, spheres, K, cmin, viol, key, index_base)
 #define SE3MPC_OBST(NN, REG, GRAD) \
-  if (wide) SE3MPC_OBST_W(NN, REG, GRAD, 8); else SE3MPC_OBST_W(NN, REG, GRAD, 3)
+  if (wide) SE3MPC_OBST_W(NN, REG, GRAD, 8); else if (four) SE3MPC_OBST_W(NN, REG, GRAD, 4); else SE3MPC_OBST_W(NN, REG, GRAD, 3)
 #define SE3MPC_OBST_N(GRAD)                                                         \
   if (!has_reg) { SE3MPC_OBST(0, false, GRAD); }                                    \
   else if (N == 6) { SE3MPC_OBST(6, true, GRAD); }                                  \
@@ -2519,7 +2523,7 @@ extern "C" int se3mpc_shooting_finish_f64(const se3mpc_params* p, int B, int ld,
 }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant >= 1536 || ((variant >> 7) & 3) == 3 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
+  if (variant < 0 || variant >= 1536 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
   se3mpc::g_rollout_variant = variant & 511;
   se3mpc::g_wide_select = variant >> 9;
   return SE3MPC_OK;

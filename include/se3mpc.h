@@ -275,8 +275,9 @@ int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uin
  * with one wavefront looping over the three axes, 6 = 32-step register bucket with guarded steps (f32, horizons 17..32;
  * else 3).  variant + 8 * (flags + 1) forces the memory-policy
  * flags of the benchmarked instantiation (horizon 30, f32, gradient): bit 0 nt loads, bit 1 nt stores,
- * bit 2 XCD-contiguous block order; the default is all three (7).  + 128 / + 256 forces the workgroup of
- * se3mpc_rollout_obstacles_* to 3 / 8 wavefronts (default: 8 while 8 x workgroups <= 1024, else 3); + 128 also forces
+ * bit 2 XCD-contiguous block order; the default is all three (7).  + 128 / + 256 / + 384 forces the workgroup of
+ * se3mpc_rollout_obstacles_* to 3 / 8 / 4 wavefronts (default: 8 while 8 x workgroups <= 1024, else 4 for the exact-N = 50 register
+ * sweep -- three axis wavefronts and a helper -- and 3 otherwise); + 128 also forces
  * se3mpc_rollout_iterate_obstacles_* to its narrow shape (3 wavefronts on 64 trajectories, sphere table in LDS; default: 7 wavefronts on
  * 32 trajectories, four of them helpers with the table in registers).  + 512 / + 1024: the
  * write-heavy float32 lane kernels never / always take their 16-byte-per-lane form (four trajectories per lane; needs B and ld
