@@ -559,7 +559,7 @@ __device__ __forceinline__ R axis_cost(const DevParams<R>& q, const RolloutSums<
 
 // One axis of one trajectory with exact-N register arrays.  Loads of all N thrust rows are issued
 // back to back (N independent HBM requests in flight per lane) before the first use.
-template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0, bool TILE = false, bool EXACT = true>
+template <typename R, int N, bool GRAD, bool STATES, int LDAUX = 0, int STAUX = 0, bool TILE = false, bool EXACT = true, bool MIDSYNC = false>
 __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
@@ -595,6 +595,7 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
       v = v + acc * q.dt;                                    // planner.py:459 solved for V_{k+1}
     }
   }
+  if (MIDSYNC) __syncthreads();                              // the position tile is complete: helper wavefronts start on it during the adjoint sweep
   s.sp += s.sterm;
   if (GRAD) {
     R lamP = (R)0, lamV = (R)0;
@@ -620,7 +621,7 @@ __device__ __forceinline__ R rollout_axis_reg(const DevParams<R>& q, int a, unsi
 
 // Any N, O(1) registers: the reverse sweep re-reads T_k (L2) and walks the states backwards
 // through the inverted recurrence instead of storing them.
-template <typename R, bool GRAD, bool STATES, int STAUX = 0, bool TILE = false>
+template <typename R, bool GRAD, bool STATES, int STAUX = 0, bool TILE = false, bool MIDSYNC = false>
 __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsigned voff, unsigned rowb, const R* __restrict__ p0,
                                               const R* __restrict__ v0, const R* __restrict__ goal,
                                               const R* __restrict__ T, R* __restrict__ gradT, R* __restrict__ Pout,
@@ -648,6 +649,7 @@ __device__ __forceinline__ R rollout_axis_rev(const DevParams<R>& q, int a, unsi
     p = p + v * q.dt + q.half_dt2 * acc;
     v = v + acc * q.dt;
   }
+  if (MIDSYNC) __syncthreads();                             // as in rollout_axis_reg
   s.sp += s.sterm;
   if (GRAD) {
     R lamP = c.two_wp * ((R)1 + q.term) * (pl - c.gl);
@@ -1316,9 +1318,10 @@ projected_step_kernel(DevParams<R> q, int B, int ld, R step, const R* __restrict
 constexpr int kSphereChunk = 8;
 
 template <typename R>
-__device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int w,
-                                               int W, int lane, R& mn_out, R& vs_out) {
-  R mn = INFINITY;
+__device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const R* __restrict__ sph, int Nn, int Kpad, int kbeg,
+                                               int kend, int kstep, int lane, R& mn_io, R& vs_io) {
+  // steps kbeg, kbeg + kstep, ... < kend; the minimum and the violation sum ACCUMULATE into mn_io / vs_io (start: +inf, 0)
+  R mn = mn_io;
   if constexpr (kObsPacked<R>) {
     typedef float f2 __attribute__((vector_size(8)));
     f2 vs2 = {0.0f, 0.0f};
@@ -1330,7 +1333,7 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
         cx[jj] = f2{s0[0], s0[4]}; cy[jj] = f2{s0[1], s0[5]}; cz[jj] = f2{s0[2], s0[6]}; r2[jj] = f2{s0[3], s0[7]};
       }
 #pragma unroll 2
-      for (int k = w; k < Nn; k += W) {
+      for (int k = kbeg; k < kend; k += kstep) {
         const float px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
                     pz = tile[((size_t)2 * Nn + k) * kWave + lane];
         const f2 px2 = {px, px}, py2 = {py, py}, pz2 = {pz, pz};
@@ -1343,7 +1346,7 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
         }
       }
     }
-    vs_out = vs2[0] + vs2[1];
+    vs_io += vs2[0] + vs2[1];
   } else {
     R vs = (R)0;
     for (int j0 = 0; j0 < Kpad; j0 += kSphereChunk) {
@@ -1353,7 +1356,7 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
         const R* s0 = sph + 4 * (j0 + jj);
         cx[jj] = s0[0]; cy[jj] = s0[1]; cz[jj] = s0[2]; r2[jj] = s0[3];
       }
-      for (int k = w; k < Nn; k += W) {
+      for (int k = kbeg; k < kend; k += kstep) {
         const R px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
                 pz = tile[((size_t)2 * Nn + k) * kWave + lane];
 #pragma unroll
@@ -1365,9 +1368,9 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
         }
       }
     }
-    vs_out = vs;
+    vs_io += vs;
   }
-  mn_out = mn;
+  mn_io = mn;
 }
 
 // Rollout fused with the sphere-obstacle residuals of planner.py:499-514 on the ROLLED-OUT positions
@@ -1377,9 +1380,13 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
 // |P_k - c_j|^2 - (r_j + margin)^2 against the LDS-resident sphere table, keeping the minimum residual and
 // the summed violation per trajectory.  Neither the states nor the N*K residuals ever touch HBM:
 // 4*(6N+12) B per rollout instead of 4*(6N+10) + 4*(3N) written + 4*(3N) re-read for the unfused pair.
-// W = 3: the axis wavefronts do everything (saturating batches).  W = 8: five more wavefronts wait at the
-// barrier and then take their share of the N*K evaluations -- for batches that leave SIMDs idle
-// (8192 rollouts = 128 workgroups) the evaluation phase is the critical path and this shortens it.
+// W = 3: the axis wavefronts do everything (saturating batches).  W > 3: W - 3 helper wavefronts put the sphere table into
+// LDS while the axis wavefronts roll out, all meet at a barrier BETWEEN the forward and the adjoint sweep (the position tile is
+// complete there), and the helpers evaluate the first `kh` steps while the axis wavefronts run the adjoint sweep and store the
+// gradient; the remaining steps are split over all W wavefronts.  kh balances the helpers' head start against the adjoint sweep
+// (~12 instructions per step and axis against 2.5 per distance evaluation): with five helpers and 16 spheres they take every step.
+// W = 8 for batches that leave SIMDs idle (8192 rollouts = 128 workgroups: the evaluation leaves the critical path), W = 4 where
+// the register sweep leaves a CU's fourth pair of wavefront slots empty.
 template <typename R, int N, bool REG, bool GRAD, int W>
 __global__ void __launch_bounds__(64 * W)
 rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
@@ -1400,15 +1407,19 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
   R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]
   R* sph = tile + (size_t)3 * q.N * kWave;                   // [Kpad][4] = (cx, cy, cz, (r + margin)^2)
   R* part = sph + (size_t)4 * Kpad;                          // [3 + 2W][64]: axis costs, then min residual / violation per wave
-  // the sphere table is fetched into registers now and written to LDS after the rollout: its HBM latency hides
-  // behind the rollout's own loads instead of preceding them (K <= 256, >= 192 threads: at most two rows each)
+  constexpr bool MID = W > 3;                               // helper wavefronts exist: barrier between the sweeps (see above)
+  constexpr int NH = MID ? W - 3 : 1;
+  // W = 3: the sphere table is fetched into registers now and written to LDS after the rollout: its HBM latency hides
+  // behind the rollout's own loads instead of preceding them (K <= 256, 192 threads: at most two rows each)
   constexpr int kRowsPerThread = (SE3MPC_MAX_SPHERES + 64 * W - 1) / (64 * W);
   R srow[kRowsPerThread][4];
+  if constexpr (!MID) {
 #pragma unroll
-  for (int t = 0; t < kRowsPerThread; ++t) {
-    const int i = threadIdx.x + t * 64 * W;
-    srow[t][0] = (R)0; srow[t][1] = (R)0; srow[t][2] = (R)0; srow[t][3] = (R)0;
-    if (i < K) { srow[t][0] = spheres[4 * i + 0]; srow[t][1] = spheres[4 * i + 1]; srow[t][2] = spheres[4 * i + 2]; srow[t][3] = spheres[4 * i + 3]; }
+    for (int t = 0; t < kRowsPerThread; ++t) {
+      const int i = threadIdx.x + t * 64 * W;
+      srow[t][0] = (R)0; srow[t][1] = (R)0; srow[t][2] = (R)0; srow[t][3] = (R)0;
+      if (i < K) { srow[t][0] = spheres[4 * i + 0]; srow[t][1] = spheres[4 * i + 1]; srow[t][2] = spheres[4 * i + 2]; srow[t][3] = spheres[4 * i + 3]; }
+    }
   }
   int blk = blockIdx.x;
   if ((gridDim.x & 7) == 0) blk = (blk & 7) * (gridDim.x >> 3) + (blk >> 3);
@@ -1422,22 +1433,42 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
   if (a < 3) {
     R* my_tile = tile + (size_t)a * Nn * kWave + lane;
     R c;
-    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, false, 2, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
-    else c = rollout_axis_rev<R, GRAD, false, 2, true>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
+    if constexpr (REG) c = rollout_axis_reg<R, N, GRAD, false, 2, 2, true, true, MID>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
+    else c = rollout_axis_rev<R, GRAD, false, 2, true, MID>(q, a, voff, rowb, p0, v0, goal, T, gradT, nullptr, nullptr, my_tile);
     part[a * kWave + lane] = c;
-  }
-#pragma unroll
-  for (int t = 0; t < kRowsPerThread; ++t) {
-    const int i = threadIdx.x + t * 64 * W;
-    if (i < Kpad) {
-      const R sm = srow[t][3] + q.margin;
-      sph[4 * i + 0] = srow[t][0]; sph[4 * i + 1] = srow[t][1]; sph[4 * i + 2] = srow[t][2];
-      sph[4 * i + 3] = i < K ? sm * sm : (R)-INFINITY;
+  } else if constexpr (MID) {
+    // helper wavefronts: the sphere table, then the barrier the axis wavefronts reach after their forward sweep
+    for (int i = (int)threadIdx.x - 3 * kWave; i < Kpad; i += NH * kWave) {
+      R s0 = (R)0, s1 = (R)0, s2 = (R)0, s3 = (R)-INFINITY;
+      if (i < K) {
+        s0 = spheres[4 * i + 0]; s1 = spheres[4 * i + 1]; s2 = spheres[4 * i + 2];
+        const R sm = spheres[4 * i + 3] + q.margin;
+        s3 = sm * sm;
+      }
+      sph[4 * i + 0] = s0; sph[4 * i + 1] = s1; sph[4 * i + 2] = s2; sph[4 * i + 3] = s3;
     }
+    __syncthreads();
   }
-  __syncthreads();
-  R mn, vs;
-  obstacle_sweep<R>(tile, sph, Nn, Kpad, a, W, lane, mn, vs);
+  R mn = INFINITY, vs = (R)0;
+  if constexpr (!MID) {
+#pragma unroll
+    for (int t = 0; t < kRowsPerThread; ++t) {
+      const int i = threadIdx.x + t * 64 * W;
+      if (i < Kpad) {
+        const R sm = srow[t][3] + q.margin;
+        sph[4 * i + 0] = srow[t][0]; sph[4 * i + 1] = srow[t][1]; sph[4 * i + 2] = srow[t][2];
+        sph[4 * i + 3] = i < K ? sm * sm : (R)-INFINITY;
+      }
+    }
+    __syncthreads();
+    obstacle_sweep<R>(tile, sph, Nn, Kpad, a, Nn, W, lane, mn, vs);
+  } else {
+    // steps [0, kh): the helpers alone, during the adjoint sweep; steps [kh, N): all W wavefronts
+    const int khb = Kpad > 0 ? (NH * 5 * Nn) / Kpad : Nn;
+    const int kh = khb < Nn ? khb : Nn;
+    if (a >= 3) obstacle_sweep<R>(tile, sph, Nn, Kpad, a - 3, kh, NH, lane, mn, vs);
+    obstacle_sweep<R>(tile, sph, Nn, Kpad, kh + a, Nn, W, lane, mn, vs);
+  }
   part[(3 + a) * kWave + lane] = mn;
   part[(3 + W + a) * kWave + lane] = vs;
   __syncthreads();
