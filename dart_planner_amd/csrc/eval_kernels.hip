@@ -1373,6 +1373,92 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
   mn_io = mn;
 }
 
+// The same residuals on the matrix core (float32).  |P_k - c_j|^2 - R_j^2 = |P_k|^2 - 2 P_k.c_j + (|c_j|^2 - R_j^2) is a K = 4 contraction of
+// (P_k, |P_k|^2) with (-2 c_j, 1) plus a per-sphere constant: ONE v_mfma_f32_16x16x4_f32 forms the residuals of 16 spheres x 16 trajectories at a
+// step, the constant riding in as the accumulator input.  A = the sphere chunk (one register per 16 spheres, loop-invariant), C-in = four
+// constants per lane, B = a row of the position tile exactly as the forward sweep stored it ([axis][k][trajectory]: lanes 0-47 read x / y / z of
+// 16 consecutive trajectories, lanes 48-63 the |P_k|^2 row this wavefront has just written behind the three axes) -- no transposed image.
+// What is left for the VALU is the fold: two v_min3 and the violation sum per four residuals, running per lane = (trajectory l % 16 of the block,
+// spheres 4 (l / 16) ... + 3) across all steps; the four lane groups meet once at the end (obstacle_mfma_fold).  Against the packed-VALU sweep
+// (10 instructions per sphere pair) this issues 8 VALU instructions + 1 MFMA per 64 residuals-per-16-lanes, i.e. 2.25 instead of 5 per residual
+// and lane, and the multiplies run beside them on the matrix pipe.  Price: the expanded form cancels, |P|^2 ~ 1e3 m^2 against a residual
+// near 0 at an obstacle's surface: float32 absolute error ~ 5e-5 m^2 there (1e-5 m of distance at R = 2.5 m) where the difference form had 1e-6.
+// MEASURED (MI355X, profiles/r03g_cfg3_mfma_vs_valu.txt): 64 x 8192 x horizon 50 x 16 spheres 163.4 us against 166.0 us for the packed-VALU sweep,
+// 1 M rollouts 330 against 336 us, the bench's ring of batches 164.4 against 161.9 us, one 8192-rollout launch 8.74 against 8.43 us -- the
+// kernel is bound by its load latency at two workgroups per CU, not by VALU issue (64 % busy), so halving the evaluation's instructions buys
+// nothing that pays for the precision.  The difference form on the VALU stays the default; se3mpc_set_rollout_variant(+2048) selects this one
+// (float32 only; float64 always takes the VALU form).
+// min(d, 0) through the integer minimum of the bit pattern (see obstacle_sweep_mfma)
+__device__ __forceinline__ float relu_neg_bits(float d) {
+  const int i = __float_as_int(d);
+  return __int_as_float(i < 0 ? i : 0);
+}
+struct ObsMfmaAcc {
+  float mn[4];
+  obs_f2 vs[4];
+};
+__device__ __forceinline__ void obstacle_mfma_init(ObsMfmaAcc& acc) {
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb) { acc.mn[tb] = INFINITY; acc.vs[tb] = obs_f2{0.0f, 0.0f}; }
+}
+__device__ __forceinline__ void obstacle_sweep_mfma(float* __restrict__ tile, const float* __restrict__ sph, int Nn, int Kpad, int kbeg, int kend,
+                                                    int kstep, int lane, ObsMfmaAcc& acc) {
+  const int li = lane & 15, lk = lane >> 4;
+  if (Kpad <= 0) return;
+  float* pprow = tile + (size_t)3 * Nn * kWave;                                    // [Nn][64]: |P_k|^2, the tile's fourth "axis"
+  // this wavefront owns steps kbeg, kbeg + kstep, ...: their |P_k|^2 rows first (read back across lanes below)
+  for (int k = kbeg; k < kend; k += kstep) {
+    const float px = tile[((size_t)0 * Nn + k) * kWave + lane], py = tile[((size_t)1 * Nn + k) * kWave + lane],
+                pz = tile[((size_t)2 * Nn + k) * kWave + lane];
+    pprow[(size_t)k * kWave + lane] = px * px + (py * py + pz * pz);
+  }
+  group_sync<kWave>();
+  for (int j0 = 0; j0 < Kpad; j0 += 16) {
+    const float* sa = sph + 4 * (j0 + li);
+    const float a = lk < 3 ? -2.0f * sa[lk] : 1.0f;                                // A[sphere li][component lk]
+    vf4 w;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* sw = sph + 4 * (j0 + 4 * lk + r);
+      w[r] = (sw[0] * sw[0] + (sw[1] * sw[1] + sw[2] * sw[2])) - sw[3];           // |c|^2 - R^2; a padding row (0, 0, 0, -inf) gives +inf
+    }
+#pragma unroll 2
+    for (int k = kbeg; k < kend; k += kstep) {
+      const float* brow = tile + ((size_t)lk * Nn + k) * kWave + li;               // lk = 3: the |P_k|^2 row
+      // the four trajectory blocks of a step: operands, then four independent matrix-core instructions, then the folds
+      float b[4];
+      vf4 d[4];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) b[tb] = brow[16 * tb];
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) d[tb] = mfma_16x16x4_f32(a, b[tb], w);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        acc.mn[tb] = __builtin_fminf(__builtin_fminf(acc.mn[tb], d[tb][0]), d[tb][1]);
+        acc.mn[tb] = __builtin_fminf(__builtin_fminf(acc.mn[tb], d[tb][2]), d[tb][3]);
+        // violation: max(0, -d) = -min(d, 0), the minimum taken on the bit patterns (a negative float is a negative integer, a positive one
+        // positive): ONE v_min_i32 per residual, the sign folded into the packed add -- fmaxf on a matrix-core result costs a canonicalising
+        // v_max first.  (A NaN residual -- non-finite positions -- with its sign bit set reaches the sum; with the bit clear it counts 0.)
+        acc.vs[tb] -= obs_f2{relu_neg_bits(d[tb][0]), relu_neg_bits(d[tb][1])};
+        acc.vs[tb] -= obs_f2{relu_neg_bits(d[tb][2]), relu_neg_bits(d[tb][3])};
+      }
+    }
+  }
+}
+// the four lane groups (sphere quarters) of every trajectory meet; lane l leaves with the totals of trajectory l
+__device__ __forceinline__ void obstacle_mfma_fold(const ObsMfmaAcc& acc, int lane, float& mn_out, float& vs_out) {
+  const int lk = lane >> 4;
+  float mn = INFINITY, vs = 0.0f;
+#pragma unroll
+  for (int tb = 0; tb < 4; ++tb) {
+    float m = acc.mn[tb], v = acc.vs[tb][0] + acc.vs[tb][1];
+    m = __builtin_fminf(m, wave_xor(m, 16)); v = v + wave_xor(v, 16);
+    m = __builtin_fminf(m, wave_xor(m, 32)); v = v + wave_xor(v, 32);
+    mn = lk == tb ? m : mn; vs = lk == tb ? v : vs;
+  }
+  mn_out = mn; vs_out = vs;
+}
+
 // Rollout fused with the sphere-obstacle residuals of planner.py:499-514 on the ROLLED-OUT positions
 // (BASELINE.json config 3: horizon 50, K = 16 spheres from the mapper).  The forward sweep of each axis
 // wavefront stages its positions as a per-step tile in LDS ([axis][k][lane], bank = lane: conflict free);
@@ -1387,7 +1473,7 @@ __device__ __forceinline__ void obstacle_sweep(const R* __restrict__ tile, const
 // (~12 instructions per step and axis against 2.5 per distance evaluation): with five helpers and 16 spheres they take every step.
 // W = 8 for batches that leave SIMDs idle (8192 rollouts = 128 workgroups: the evaluation leaves the critical path), W = 4 where
 // the register sweep leaves a CU's fourth pair of wavefront slots empty.
-template <typename R, int N, bool REG, bool GRAD, int W>
+template <typename R, int N, bool REG, bool GRAD, int W, bool MF = false>
 __global__ void __launch_bounds__(64 * W)
 rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0, const R* __restrict__ v0,
                          const R* __restrict__ goal, const R* __restrict__ T, R* __restrict__ cost,
@@ -1403,9 +1489,11 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
     if (viol != nullptr) viol += bi * (size_t)ld;
     if (key != nullptr) key += bi * (size_t)gridDim.x;
   }
-  const int Kpad = (K + kSphereChunk - 1) / kSphereChunk * kSphereChunk;
-  R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]
-  R* sph = tile + (size_t)3 * q.N * kWave;                   // [Kpad][4] = (cx, cy, cz, (r + margin)^2)
+  static_assert(!MF || sizeof(R) == 4, "the matrix-core sweep is float32");
+  constexpr int kChunk = MF ? 16 : kSphereChunk;            // MF: residuals on the matrix core, 16 spheres per instruction (obstacle_sweep_mfma)
+  const int Kpad = (K + kChunk - 1) / kChunk * kChunk;
+  R* tile = reinterpret_cast<R*>(lds_raw);                  // [3][N][64]; MF: [4][N][64], the fourth block = |P_k|^2
+  R* sph = tile + (size_t)(MF ? 4 : 3) * q.N * kWave;        // [Kpad][4] = (cx, cy, cz, (r + margin)^2)
   R* part = sph + (size_t)4 * Kpad;                          // [3 + 2W][64]: axis costs, then min residual / violation per wave
   constexpr bool MID = W > 3;                               // helper wavefronts exist: barrier between the sweeps (see above)
   constexpr int NH = MID ? W - 3 : 1;
@@ -1461,13 +1549,30 @@ rollout_obstacles_kernel(DevParams<R> q, int B, int ld, const R* __restrict__ p0
       }
     }
     __syncthreads();
-    obstacle_sweep<R>(tile, sph, Nn, Kpad, a, Nn, W, lane, mn, vs);
+    if constexpr (MF) {
+      ObsMfmaAcc acc;
+      obstacle_mfma_init(acc);
+      obstacle_sweep_mfma(tile, sph, Nn, Kpad, a, Nn, W, lane, acc);
+      obstacle_mfma_fold(acc, lane, mn, vs);
+    } else {
+      obstacle_sweep<R>(tile, sph, Nn, Kpad, a, Nn, W, lane, mn, vs);
+    }
   } else {
-    // steps [0, kh): the helpers alone, during the adjoint sweep; steps [kh, N): all W wavefronts
-    const int khb = Kpad > 0 ? (NH * 5 * Nn) / Kpad : Nn;
+    // steps [0, kh): the helpers alone, during the adjoint sweep; steps [kh, N): all W wavefronts.  The adjoint sweep costs an axis wavefront
+    // ~48 cycles per step; a step's residuals cost ~9 cycles per sphere on the matrix core (150 per 16 spheres), ~20 on the VALU (320):
+    // the head start covers 5 N / Kpad steps per helper there, 2.5 N / Kpad here
+    const int khb = Kpad > 0 ? (NH * (MF ? 10 : 5) * Nn) / (2 * Kpad) : Nn;
     const int kh = khb < Nn ? khb : Nn;
-    if (a >= 3) obstacle_sweep<R>(tile, sph, Nn, Kpad, a - 3, kh, NH, lane, mn, vs);
-    obstacle_sweep<R>(tile, sph, Nn, Kpad, kh + a, Nn, W, lane, mn, vs);
+    if constexpr (MF) {
+      ObsMfmaAcc acc;
+      obstacle_mfma_init(acc);
+      if (a >= 3) obstacle_sweep_mfma(tile, sph, Nn, Kpad, a - 3, kh, NH, lane, acc);
+      obstacle_sweep_mfma(tile, sph, Nn, Kpad, kh + a, Nn, W, lane, acc);
+      obstacle_mfma_fold(acc, lane, mn, vs);
+    } else {
+      if (a >= 3) obstacle_sweep<R>(tile, sph, Nn, Kpad, a - 3, kh, NH, lane, mn, vs);
+      obstacle_sweep<R>(tile, sph, Nn, Kpad, kh + a, Nn, W, lane, mn, vs);
+    }
   }
   part[(3 + a) * kWave + lane] = mn;
   part[(3 + W + a) * kWave + lane] = vs;
@@ -1915,6 +2020,7 @@ static inline int check_lane_args(const se3mpc_params* p, int B, int ld, long lo
 // lane against 5.1-5.5 with a dword).  float only; taken when B and ld are multiples of 4, the operands 16-byte aligned and the batch fills
 // the chip with a quarter of the wavefronts (kWideMinBatch); the arithmetic per trajectory is the dword kernel's, statement for statement.
 constexpr int kWideMinBatch = 1 << 18;
+static int g_obs_mfma = 0;           // se3mpc_set_rollout_variant(+2048): se3mpc_rollout_obstacles_* forms its float32 residuals on the matrix core (expanded form; measured evidence, not the default)
 static int g_wide_select = 0;        // se3mpc_set_rollout_variant(+512 / +1024): never / whenever the shapes allow (default: from kWideMinBatch up)
 static bool wide_ok(int B, int ld, std::initializer_list<const void*> ptrs) {
   if (g_wide_select == 1 || (g_wide_select == 0 && B < kWideMinBatch) || B < 4 || (B & 3) || (ld & 3)) return false;
@@ -2205,13 +2311,27 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
   // a helper: profiles/r03f_cfg3_workgroup_shapes.txt); se3mpc_set_rollout_variant(+384) forces it
   const bool four = wsel == 3 || (wsel == 0 && !wide && has_reg && N == 50);
   const int W = wide ? 8 : (four ? 4 : 3);
-  const size_t lds = ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
+  // se3mpc_set_rollout_variant(+2048), float32: the residuals on the matrix core (obstacle_sweep_mfma: a fourth tile block for |P_k|^2, the
+  // table padded to 16) unless the larger LDS image would pass 64 KiB.  Not the default: measured equal to the packed-VALU difference form
+  // within 2 % either way (profiles/r03g_cfg3_mfma_vs_valu.txt) at four decimal digits less next to an obstacle's surface
+  const int Kpad16 = (K + 15) / 16 * 16;
+  const size_t lds_mf = ((size_t)4 * N * kWave + (size_t)4 * Kpad16 + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
+  const bool mf = sizeof(R) == 4 && g_obs_mfma && K > 0 && lds_mf <= 64 * 1024;
+  const size_t lds = mf ? lds_mf : ((size_t)3 * N * kWave + (size_t)4 * Kpad + (size_t)(3 + 2 * W) * kWave) * sizeof(R);
   hipStream_t s = (hipStream_t)stream;
-#define SE3MPC_OBST_W(NN, REG, GRAD, WW)                                                                                 \
-  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW>), dim3(nblk, nbatch), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
+#define SE3MPC_OBST_L(NN, REG, GRAD, WW, MFF)                                                                                \
+  hipLaunchKernelGGL((rollout_obstacles_kernel<R, NN, REG, GRAD, WW, MFF>), dim3(nblk, nbatch), dim3(64 * WW), lds, s, q, B, ld, p0, v0, \
                      goal, T, cost, gradT, spheres, K, cmin, viol, key, index_base)
+#define SE3MPC_OBST_W(NN, REG, GRAD, WW)                                                                 \
+  {                                                                                                      \
+    if constexpr (sizeof(R) == 4) {                                                                      \
+      if (mf) { SE3MPC_OBST_L(NN, REG, GRAD, WW, true); } else { SE3MPC_OBST_L(NN, REG, GRAD, WW, false); } \
+    } else {                                                                                             \
+      SE3MPC_OBST_L(NN, REG, GRAD, WW, false);                                                           \
+    }                                                                                                    \
+  }
 #define SE3MPC_OBST(NN, REG, GRAD) \
-  if (wide) SE3MPC_OBST_W(NN, REG, GRAD, 8); else if (four) SE3MPC_OBST_W(NN, REG, GRAD, 4); else SE3MPC_OBST_W(NN, REG, GRAD, 3)
+  { if (wide) SE3MPC_OBST_W(NN, REG, GRAD, 8) else if (four) SE3MPC_OBST_W(NN, REG, GRAD, 4) else SE3MPC_OBST_W(NN, REG, GRAD, 3) }
 #define SE3MPC_OBST_N(GRAD)                                                         \
   if (!has_reg) { SE3MPC_OBST(0, false, GRAD); }                                    \
   else if (N == 6) { SE3MPC_OBST(6, true, GRAD); }                                  \
@@ -2223,6 +2343,7 @@ int rollout_obstacles_impl(const se3mpc_params* p, int B, int ld, const R* p0, c
 #undef SE3MPC_OBST_N
 #undef SE3MPC_OBST
 #undef SE3MPC_OBST_W
+#undef SE3MPC_OBST_L
   return launch_status("se3mpc_rollout_obstacles");
 }
 
@@ -2554,9 +2675,10 @@ extern "C" int se3mpc_shooting_finish_f64(const se3mpc_params* p, int B, int ld,
 }
 
 extern "C" int se3mpc_set_rollout_variant(int variant) {
-  if (variant < 0 || variant >= 1536 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
+  if (variant < 0 || variant >= 4096 || ((variant >> 9) & 3) == 3 || (variant & 127) > 71 || (variant & 7) > 6) return SE3MPC_ERR_SHAPE;
   se3mpc::g_rollout_variant = variant & 511;
-  se3mpc::g_wide_select = variant >> 9;
+  se3mpc::g_wide_select = (variant >> 9) & 3;
+  se3mpc::g_obs_mfma = (variant >> 11) & 1;
   return SE3MPC_OK;
 }
 

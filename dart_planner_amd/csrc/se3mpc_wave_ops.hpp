@@ -300,6 +300,12 @@ __device__ __forceinline__ void lane_st4(vf4* p, vf4 v) { __builtin_nontemporal_
 __device__ __forceinline__ vf4 splat4(float x) { return (vf4)(x); }
 
 // 1 / x: one v_rcp_f32 (1 ulp) for float where a kernel's float32 tolerance allows it, the IEEE quotient for double
+// ---- matrix core: v_mfma_f32_16x16x4_f32, D(16x16) = A(16x4) B(4x16) + C, full float32 multiply-adds.  Lane l supplies a = A[l % 16][l / 16] and
+// b = B[l / 16][l % 16]; register r of c / d is C / D[4 (l / 16) + r][l % 16].  Every lane of the wavefront must be active.
+__device__ __forceinline__ vf4 mfma_16x16x4_f32(float a, float b, vf4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// value of lane (l ^ mask) of the same wavefront
+__device__ __forceinline__ float wave_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
+
 __device__ __forceinline__ float rcp_approx(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ double rcp_approx(double x) { return 1.0 / x; }
 

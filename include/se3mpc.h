@@ -282,6 +282,8 @@ int se3mpc_reduce_keys(const uint64_t* wave_keys, int per_batch, int nbatch, uin
  * 32 trajectories, four of them helpers with the table in registers).  + 512 / + 1024: the
  * write-heavy float32 lane kernels never / always take their 16-byte-per-lane form (four trajectories per lane; needs B and ld
  * multiples of 4 and 16-byte aligned operands; default: from 262144 trajectories up).
+ * + 2048: se3mpc_rollout_obstacles_f32 forms its residuals on the matrix core (v_mfma_f32_16x16x4_f32 on the expanded form |P|^2 - 2 P.c + |c|^2 - R^2:
+ * measured evidence for DESIGN.md 5.3, no faster than the default packed-VALU difference form and four digits less precise next to a sphere's surface).
  * All compute the same quantities. */
 int se3mpc_set_rollout_variant(int variant);
 

@@ -197,6 +197,8 @@ void launch(K kernel, dim3 grid, dim3 block, size_t shmem, Args... args) {
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) ::emu::launch(kernel, grid, block, (size_t)(shmem), __VA_ARGS__)
 
 inline void __syncthreads() { ::emu::sync(); }
+inline int __float_as_int(float f) { int u; std::memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 

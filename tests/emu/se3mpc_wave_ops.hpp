@@ -95,6 +95,23 @@ SE3MPC_EMU_VF4_OP(-)
 SE3MPC_EMU_VF4_OP(*)
 SE3MPC_EMU_VF4_OP(/)
 #undef SE3MPC_EMU_VF4_OP
+// matrix core (product header: v_mfma_f32_16x16x4_f32): the wavefront's 64 lanes deposit their operands, rendezvous, and every lane forms its four outputs
+inline float g_mfma_a[1024], g_mfma_b[1024];
+inline vf4 mfma_16x16x4_f32(float a, float b, vf4 c) {
+  const int me = (int)threadIdx.x, l = me % 64, base = me - l;
+  g_mfma_a[me] = a; g_mfma_b[me] = b;
+  ::emu::sync_group(base, 64);
+  vf4 d = c;
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (l / 16) + r, j = l % 16;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = __builtin_fmaf(g_mfma_a[base + 16 * k + i], g_mfma_b[base + 16 * k + j], acc);
+    d[r] = acc;
+  }
+  ::emu::sync_group(base, 64);
+  return d;
+}
+inline float wave_xor(float v, int mask) { const int me = (int)threadIdx.x, l = me % 64, base = me - l; return ::emu::exchange_group(v, base + (l ^ mask), base, 64); }
 inline float rcp_approx(float x) { return 1.0f / x; }
 inline double rcp_approx(double x) { return 1.0 / x; }
 inline vf4 lane_ld4(const vf4* p) { return *p; }

@@ -224,7 +224,8 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
     #  during the adjoint sweep; sphere counts that are not a multiple of the register chunk of 8, and few enough that the helpers take every step)
     Cr_all = orc.obstacle_residual(orc.pack(P_ref, V_ref, T), sph[:, :3], sph[:, 3], cfg).reshape(B, N, -1)
     try:
-        for wsel, Ks in ((128, len(sph)), (256, len(sph)), (384, len(sph)), (128, 3), (256, 9), (384, 9), (384, 1), (256, 2), (0, len(sph))):
+        for wsel, Ks in ((128, len(sph)), (256, len(sph)), (384, len(sph)), (128, 3), (256, 9), (384, 9), (384, 1), (256, 2), (0, len(sph)),
+                         (2048 + 128, len(sph)), (2048 + 256, 9), (2048 + 384, len(sph))):     # + 2048: float32 residuals on the matrix core (expanded form), not the packed-VALU difference form
             h.ops.lib.set_rollout_variant(wsel)
             co, go, cmn, vio = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
                                                        h.prob(sph[:Ks]))
@@ -236,7 +237,7 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
         # 40 spheres: more than the helper wavefronts' head start covers, so that both shapes also split steps over all wavefronts
         sph40 = np.concatenate([sph, sph + np.array([0.25, -0.25, 0.5, 0.0]), sph[:8] - np.array([0.5, 0.5, 0.25, 0.0])])
         Cr40 = orc.obstacle_residual(orc.pack(P_ref, V_ref, T), sph40[:, :3], sph40[:, 3], cfg).reshape(B, -1)
-        for wsel in (128, 256, 384):
+        for wsel in (128, 256, 384, 2048 + 256, 2048 + 384):
             h.ops.lib.set_rollout_variant(wsel)
             _, _, cmn, vio = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B), h.prob(sph40))
             vec_close(h.to_host(cmn), Cr40.min(1), t["vec_rel"] * 4, f"fused obstacle min (variant {wsel}, K=40)")

@@ -1,5 +1,5 @@
 """Developer probe (GPU box): BASELINE config 3 one-shot (se3mpc_rollout_obstacles_*: rollout + cost + gradient + sphere residuals) at the
-batched size of bench.py's `configs.cfg3.batched` leg (64 x 8192), by workgroup shape (3 / 4 / 8 wavefronts) and rollout form (exact-N registers /
+batched size of bench.py's `configs.cfg3.batched` leg (64 x 8192), by workgroup shape (3 / 4 / 8 wavefronts), residual form (packed VALU / + 2048: matrix core) and rollout form (exact-N registers /
 register-light reversible sweep).  `python3 tools/gpu_probe_cfg3_batched.py [nbatch] [B] [N]`."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -29,6 +29,7 @@ def timed(fn, reps=20):
 
 cost = torch.empty(nb, B, device=dev); grad = torch.empty_like(T); cmin = torch.empty(nb, B, device=dev); viol = torch.empty(nb, B, device=dev)
 VARIANTS = (("registers, auto shape", 0), ("registers, 3 wavefronts", 128), ("registers, 8 wavefronts", 256), ("registers, 4 wavefronts", 384),
+            ("registers, 3 wavefronts, matrix-core residuals", 128 + 2048), ("registers, 4 wavefronts, matrix-core residuals", 384 + 2048), ("registers, 8 wavefronts, matrix-core residuals", 256 + 2048),
             ("reversible sweep, 3 wavefronts", 3 + 128), ("reversible sweep, 8 wavefronts", 3 + 256), ("reversible sweep, 4 wavefronts", 3 + 384))
 # three interleaved rounds (the first timing of a process runs on a cold clock / page state: the same kernel measured 85 and 110 us in one list)
 times = {name: [] for name, _ in VARIANTS}
