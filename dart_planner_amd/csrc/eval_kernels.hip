@@ -1470,7 +1470,8 @@ __device__ __forceinline__ void obstacle_mfma_fold(const ObsMfmaAcc& acc, int la
 // LDS while the axis wavefronts roll out, all meet at a barrier BETWEEN the forward and the adjoint sweep (the position tile is
 // complete there), and the helpers evaluate the first `kh` steps while the axis wavefronts run the adjoint sweep and store the
 // gradient; the remaining steps are split over all W wavefronts.  kh balances the helpers' head start against the adjoint sweep
-// (~12 instructions per step and axis against 2.5 per distance evaluation): with five helpers and 16 spheres they take every step.
+// (measured per-step costs, see where it is formed): with five helpers and 16 spheres they take most of the steps.  MF: the residuals on the
+// matrix core (obstacle_sweep_mfma; float32, se3mpc_set_rollout_variant(+2048)) instead of the packed-VALU difference form.
 // W = 8 for batches that leave SIMDs idle (8192 rollouts = 128 workgroups: the evaluation leaves the critical path), W = 4 where
 // the register sweep leaves a CU's fourth pair of wavefront slots empty.
 template <typename R, int N, bool REG, bool GRAD, int W, bool MF = false>

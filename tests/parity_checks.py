@@ -242,6 +242,14 @@ def check_lane_kernels(h: Harness, N: int, B: int, seed: int = 0, variants=(0,),
             _, _, cmn, vio = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B), h.prob(sph40))
             vec_close(h.to_host(cmn), Cr40.min(1), t["vec_rel"] * 4, f"fused obstacle min (variant {wsel}, K=40)")
             vec_close(h.to_host(vio), np.maximum(0, -Cr40).sum(1), t["vec_rel"] * 8, f"fused obstacle violation (variant {wsel}, K=40)")
+        # the largest table the entry point takes (SE3MPC_MAX_SPHERES = 256): sixteen shifted copies of the scene
+        sph256 = np.concatenate([sph + np.array([0.5 * i, -0.25 * i, 0.125 * i, 0.0]) for i in range(16)])
+        Cr256 = orc.obstacle_residual(orc.pack(P_ref, V_ref, T), sph256[:, :3], sph256[:, 3], cfg).reshape(B, -1)
+        for wsel in (0, 384, 2048 + 384):
+            h.ops.lib.set_rollout_variant(wsel)
+            _, _, cmn, vio = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B), h.prob(sph256))
+            vec_close(h.to_host(cmn), Cr256.min(1), t["vec_rel"] * 4, f"fused obstacle min (variant {wsel}, K=256)")
+            vec_close(h.to_host(vio), np.maximum(0, -Cr256).sum(1), t["vec_rel"] * 8, f"fused obstacle violation (variant {wsel}, K=256)")
     finally:
         h.ops.lib.set_rollout_variant(0)
     co2, g_none, cmn2, _ = h.ops.rollout_obstacles(prm, h.lane(p0, B), h.lane(v0, B), h.lane(goal, B), h.lane(T, B),
