@@ -23,7 +23,8 @@ Launches are captured once into a hipGraph and replayed inside the timed region.
 The launch shape never depends on `--steps`: a *pass* is ceil(K / S) full S-batch launches, and the pass is
 repeated (`repeats`) until the timed region lasts at least `--min-ms` (20 ms), so a driver that asks for
 K = 20 steps measures the same steady state as K = 20000; `steps` echoes K, `steps_timed` is what ran,
-`ms_per_step` is the mean over the steps that ran.
+`ms_per_step` is the mean over the steps that ran.  Every device-time leg (the timed region included) is preceded by ~60 ms of
+its own load, untimed (`warm_device`): after the idle gap of a graph capture the card needs 20-40 ms before a kernel's duration settles.
 
 `--gpus N` with N > 1 and no torchrun environment: bench.py starts
 `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself, as a child process and BEFORE
